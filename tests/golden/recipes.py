@@ -1,0 +1,125 @@
+"""Seeded input recipes shared by make_golden.py (which runs the reference on them
+in the build container) and by the tests (which regenerate the same inputs and
+compare against the committed expected outputs).  Each golden file stores the
+SHA-256 of the input bytes so that a drift in the generator is detected rather
+than silently compared against stale expectations.
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+D = 1024
+
+
+def sha256(*arrays) -> str:
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+# ------------------------------------------------------------------ scan (a9)
+def scan_case(name: str):
+    """-> (query, store, k) for a named top-k case."""
+    if name in ("n4096_k5", "n4096_k32", "n4096_k32_f64store"):
+        rng = np.random.default_rng(1234)
+        store = rng.standard_normal((4096, D), dtype=np.float32)
+        query = rng.standard_normal(D, dtype=np.float32)
+        if name.endswith("f64store"):
+            store = store.astype(np.float64)      # dtype after load_theta_event (:391-395)
+        return query, store, (5 if name == "n4096_k5" else 32)
+    if name == "n300_k5_unitrows":
+        # shape of a real event: a few hundred unit-norm frame embeddings, k=5 (:3153)
+        rng = np.random.default_rng(77)
+        store = rng.standard_normal((300, D)).astype(np.float32)
+        store /= np.linalg.norm(store, axis=1, keepdims=True)
+        query = (store[17] + 0.3 * rng.standard_normal(D)).astype(np.float32)
+        return query, store, 5
+    if name == "k_gt_n":
+        rng = np.random.default_rng(5)
+        return rng.standard_normal(D, dtype=np.float32), rng.standard_normal((7, D), dtype=np.float32), 32
+    if name == "store_1d":
+        rng = np.random.default_rng(6)
+        return rng.standard_normal(D, dtype=np.float32), rng.standard_normal(D, dtype=np.float32), 5
+    if name == "duplicate_rows":
+        rng = np.random.default_rng(8)
+        store = rng.standard_normal((12, D), dtype=np.float32)
+        query = (store[3] + 0.1 * rng.standard_normal(D, dtype=np.float32)).astype(np.float32)
+        store[9] = store[3]                         # exact tie at rank 1/2
+        store[5] = store[3]
+        return query, store, 4
+    if name == "zero_row":
+        rng = np.random.default_rng(9)
+        store = rng.standard_normal((10, D), dtype=np.float32)
+        store[4] = 0.0                              # 0/0 -> NaN similarity
+        return rng.standard_normal(D, dtype=np.float32), store, 3
+    raise KeyError(name)
+
+
+SCAN_CASES = ["n4096_k5", "n4096_k32", "n4096_k32_f64store", "n300_k5_unitrows",
+              "k_gt_n", "store_1d", "duplicate_rows", "zero_row"]
+
+
+# ------------------------------------------------------------- select (a7)
+def clustered(n: int, n_clusters: int, sigma: float, seed: int) -> np.ndarray:
+    """Time-ordered frames that dwell on `n_clusters` scenes: consecutive runs of
+    near-duplicates (centre + sigma * noise), so that consolidation drops frames."""
+    rng = np.random.default_rng(seed)
+    centres = rng.standard_normal((n_clusters, D)).astype(np.float32)
+    centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+    which = (np.arange(n) * n_clusters) // n
+    noise = rng.standard_normal((n, D)).astype(np.float32) * np.float32(sigma / np.sqrt(D))
+    return (centres[which] + noise).astype(np.float32)
+
+
+def select_case(name: str):
+    """-> (features fp32 (n,1024), times float64 (n,))."""
+    if name in ("n1", "n2", "n3"):
+        n = int(name[1:])
+        f = np.random.default_rng(20 + n).standard_normal((n, D), dtype=np.float32)
+    elif name == "n32_clusters6":
+        f = clustered(32, 6, 0.2, 7)                 # BASELINE cfg 1 shape
+    elif name == "n257_clusters40":
+        f = clustered(257, 40, 0.25, 11)
+    elif name == "n3600_clusters600":
+        f = clustered(3600, 600, 0.2, 13)            # BASELINE cfg 5 shape
+    elif name == "n64_revisit":
+        # scenes revisited later in time: the kept set must block late near-duplicates
+        base = clustered(16, 4, 0.15, 31)
+        f = np.concatenate([base, base[::-1] + np.float32(1e-3), base, base[::2].repeat(2, 0)])
+    elif name == "n40_all_distinct":
+        f = np.random.default_rng(41).standard_normal((40, D), dtype=np.float32)
+    elif name == "n40_all_same":
+        v = np.random.default_rng(42).standard_normal(D).astype(np.float32)
+        f = np.tile(v, (40, 1)) * np.linspace(0.5, 2.0, 40, dtype=np.float32)[:, None]
+    elif name == "n24_duplicates":
+        f = clustered(24, 24, 0.0, 43)
+        f[7] = f[2]
+        f[15] = f[2]
+        f[23] = f[11]
+    elif name == "n20_near_threshold":
+        # one pair placed 1e-4 either side of 0.9 (outside the BLAS-order band)
+        rng = np.random.default_rng(44)
+        f = rng.standard_normal((20, D)).astype(np.float32)
+        f /= np.linalg.norm(f, axis=1, keepdims=True)
+        def at_cos(u, c, seed):
+            r = np.random.default_rng(seed).standard_normal(D)
+            r -= r.dot(u) * u
+            r /= np.linalg.norm(r)
+            return (c * u + np.sqrt(1 - c * c) * r).astype(np.float32)
+        f[5] = at_cos(f[1].astype(np.float64), 0.9 + 1e-4, 1)
+        f[9] = at_cos(f[3].astype(np.float64), 0.9 - 1e-4, 2)
+    elif name == "n12_zero_row":
+        f = clustered(12, 5, 0.2, 45)
+        f[6] = 0.0                                  # NaN row: never kept, blocks nobody later
+    else:
+        raise KeyError(name)
+    n = f.shape[0]
+    return np.ascontiguousarray(f, dtype=np.float32), np.arange(n, dtype=np.float64)
+
+
+SELECT_CASES = ["n1", "n2", "n3", "n32_clusters6", "n257_clusters40", "n3600_clusters600",
+                "n64_revisit", "n40_all_distinct", "n40_all_same", "n24_duplicates",
+                "n20_near_threshold", "n12_zero_row"]
