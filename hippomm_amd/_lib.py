@@ -1,0 +1,79 @@
+"""ctypes binding of libhippomm_hip.so (C ABI: include/hippomm_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libhippomm_hip.so"
+
+_lib = None
+
+c_f32p = C.c_void_p       # device pointers travel as integers (tensor.data_ptr())
+c_ptr = C.c_void_p
+
+_SIGNATURES = {
+    "hmm_abi_version": (C.c_int, []),
+    "hmm_last_error": (C.c_char_p, []),
+    "hmm_cosine_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "hmm_cosine_topk": (C.c_int, [c_ptr, C.c_int64, C.c_int, c_ptr, C.c_int, c_ptr, c_ptr, c_ptr,
+                                  c_ptr, C.c_size_t, c_ptr]),
+    "hmm_cosine_topk_keys": (C.c_int, [c_ptr, C.c_int64, C.c_int, c_ptr, C.c_int, c_ptr,
+                                       c_ptr, C.c_size_t, c_ptr]),
+    "hmm_topk_merge_keys": (C.c_int, [c_ptr, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "hmm_gram_select_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "hmm_gram_select": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_float, c_ptr, c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "hmm_encoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "hmm_encoder_destroy": (None, [c_ptr]),
+    "hmm_encoder_load_param": (C.c_int, [c_ptr, C.c_char_p, c_ptr, C.c_int64, c_ptr]),
+    "hmm_encoder_missing_params": (C.c_int, [c_ptr]),
+    "hmm_encoder_workspace_bytes": (C.c_size_t, [c_ptr, C.c_int]),
+    "hmm_encoder_forward": (C.c_int, [c_ptr, c_ptr, C.c_int, c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "hmm_encoder_flops": (C.c_double, [c_ptr, C.c_int]),
+    "hmm_op_gemm_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
+    "hmm_op_layernorm_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr]),
+    "hmm_op_attention_bf16": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr]),
+}
+
+
+class HippoMMHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise HippoMMHipError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -m hippomm_amd.build). "
+            "hippomm_amd has no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI and the binding disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = load().hmm_last_error().decode("utf-8", "replace")
+        raise HippoMMHipError(f"{what} failed (status {status}): {msg}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise HippoMMHipError("hippomm_amd needs a ROCm GPU (MI355X / gfx950); no CPU fallback exists")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,54 @@
+"""Consolidation similarity on MI355X -- host-side mirror of
+``HippocampalMemory._select_key_frames`` (hippomm/core/hippocampal_memory.py:944-967),
+bound to ``hmm_gram_select`` (fp32 normalise, fp64-accumulated gram via f64 MFMA, greedy scan).
+"""
+from __future__ import annotations
+
+from typing import Optional, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+
+FEATURE_DIM = 1024
+
+
+def select_key_frames_device(features: torch.Tensor, similarity_threshold: float = 0.9) -> torch.Tensor:
+    """features: (n,1024) fp32 CUDA tensor -> kept indices int64 CUDA tensor (synchronises once
+    to read the count)."""
+    lib = _lib.load()
+    if features.dim() != 2 or features.shape[1] != FEATURE_DIM:
+        raise ValueError(f"features must be (n,{FEATURE_DIM}), got {tuple(features.shape)}")
+    f = features.to(dtype=torch.float32).contiguous()
+    n = f.shape[0]
+    dev = f.device
+    kept = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    n_kept = torch.zeros(1, dtype=torch.int32, device=dev)
+    need = lib.hmm_gram_select_workspace_bytes(n)
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    thr = float(np.float32(similarity_threshold))     # the reference compares in float32 (:960)
+    _lib.check(lib.hmm_gram_select(f.data_ptr(), n, FEATURE_DIM, thr, kept.data_ptr(), n_kept.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "hmm_gram_select")
+    return kept[: int(n_kept.item())]
+
+
+def select_key_frames(features: Union[np.ndarray, torch.Tensor], times: Optional[np.ndarray] = None,
+                      similarity_threshold: float = 0.9) -> np.ndarray:
+    """Same contract as the reference method: int64 indices, increasing, first is 0; ``times`` is
+    accepted and unused, as in the reference."""
+    if len(features) <= 2:                              # :947-948
+        return np.arange(len(features))
+    dev = _lib.require_gpu()
+    if isinstance(features, np.ndarray):
+        f = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(dev)
+    else:
+        f = features.to(dev)
+    return select_key_frames_device(f, similarity_threshold).cpu().numpy()
+
+
+def _select_key_frames(self, features: np.ndarray, times: np.ndarray,
+                       similarity_threshold: float = 0.9) -> np.ndarray:
+    """Drop-in for ``HippocampalMemory._select_key_frames`` (assign it on the class; ``self`` is
+    unused there as well)."""
+    return select_key_frames(features, times, similarity_threshold)

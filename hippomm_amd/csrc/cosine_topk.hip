@@ -1,0 +1,326 @@
+// feature_search scan for gfx950: one streaming pass over the (N,1024) fp32 store computing
+// dot(row,q) and sum(row^2) per row, then an exact top-k under a documented total order.
+// Replaces top_k_cosine_similarity (reference hippomm/utils/vector_ops.py:151-188).
+//
+// Kernels
+//   scan_sims_kernel   HBM-bound.  One wave per row: lane l reads the four float4 at
+//                      columns 4*(64*j + l), j=0..3, so every load instruction of a wave covers
+//                      1 KiB contiguous.  Two rows (8 x 16 B loads per lane) are in flight per
+//                      wave, 32 waves per CU.  Algorithmic bytes: 4096 B per row, read once.
+//   topk_chunk_kernel  4096-key bitonic sort in LDS per block, keeps the best k of each chunk;
+//                      applied repeatedly until one chunk is left (N=1M, k=32: 245 -> 2 -> 1).
+//   bitonic_global_*   rare path (k > 1024 and N > 4096): full sort of all keys.
+//   decode_kernel      keys -> (int64 row, fp32 sim).
+// Keys are 64-bit: (order_bits(sim) << 32) | row, so "larger key" == "better, higher row first
+// on ties, NaN first"; 0 is the padding key (no valid row maps to it).
+#include "hmm_common.h"
+
+namespace hmm {
+
+constexpr int kChunk = 4096;      // keys sorted per block
+constexpr int kFastK = 1024;      // chunk-tournament path handles k <= kFastK
+constexpr int kScanBlocks = kNumCU * 8;
+
+template <bool NT>
+__device__ __forceinline__ float4 ld16(const float4* p) {
+    if constexpr (NT) {
+        f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        return *p;
+    }
+}
+
+__device__ __forceinline__ void fma4(float& dot, float& ss, const float4& x, const float4& q) {
+    dot = fmaf(x.x, q.x, dot); ss = fmaf(x.x, x.x, ss);
+    dot = fmaf(x.y, q.y, dot); ss = fmaf(x.y, x.y, ss);
+    dot = fmaf(x.z, q.z, dot); ss = fmaf(x.z, x.z, ss);
+    dot = fmaf(x.w, q.w, dot); ss = fmaf(x.w, x.w, ss);
+}
+
+// sims[r] = dot(store[r], q) / (||store[r]|| * ||q||)     (vector_ops.py:178-182)
+template <bool NT>
+__global__ __launch_bounds__(256) void scan_sims_kernel(const float4* __restrict__ store,
+                                                        int64_t n_rows,
+                                                        const float4* __restrict__ query,
+                                                        float* __restrict__ sims) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+
+    float4 q[4];
+    float qs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        q[j] = query[j * 64 + lane];
+        qs = fmaf(q[j].x, q[j].x, qs); qs = fmaf(q[j].y, q[j].y, qs);
+        qs = fmaf(q[j].z, q[j].z, qs); qs = fmaf(q[j].w, q[j].w, qs);
+    }
+    const float q_len = sqrtf(wave_sum(qs));
+
+    for (int64_t r = wave * 2; r < n_rows; r += n_waves * 2) {
+        const bool two = (r + 1) < n_rows;                  // wave-uniform
+        const float4* p0 = store + r * 256 + lane;
+        const float4* p1 = p0 + (two ? 256 : 0);
+        float4 a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = ld16<NT>(p0 + j * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = ld16<NT>(p1 + j * 64);
+        float d0 = 0.f, s0 = 0.f, d1 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fma4(d0, s0, a[j], q[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fma4(d1, s1, b[j], q[j]);
+        d0 = wave_sum(d0); s0 = wave_sum(s0);
+        d1 = wave_sum(d1); s1 = wave_sum(s1);
+        if (lane == 0) {
+            sims[r] = d0 / (sqrtf(s0) * q_len);
+            if (two) sims[r + 1] = d1 / (sqrtf(s1) * q_len);
+        }
+    }
+}
+
+// Descending bitonic sort of N keys in LDS by NT threads.
+template <int N, int NT>
+__device__ __forceinline__ void bitonic_sort_desc(uint64_t* s) {
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < N / 2; t += NT) {
+                const int i = 2 * t - (t & (j - 1));
+                const int l = i + j;
+                const bool desc = (i & k) == 0;
+                const uint64_t a = s[i], b = s[l];
+                if ((a < b) == desc) { s[i] = b; s[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Each block sorts one chunk and writes its best `k` keys (0-padded) to out[blockIdx.x*k ..].
+template <bool FROM_SIMS>
+__global__ __launch_bounds__(256) void topk_chunk_kernel(const void* __restrict__ in, int64_t n_in,
+                                                         int k, uint64_t* __restrict__ out) {
+    __shared__ uint64_t s[kChunk];
+    const int64_t base = (int64_t)blockIdx.x * kChunk;
+    for (int t = threadIdx.x; t < kChunk; t += 256) {
+        const int64_t g = base + t;
+        uint64_t key = 0;
+        if (g < n_in) {
+            if constexpr (FROM_SIMS) {
+                const float v = static_cast<const float*>(in)[g];
+                key = ((uint64_t)order_bits(v) << 32) | (uint64_t)(uint32_t)g;
+            } else {
+                key = static_cast<const uint64_t*>(in)[g];
+            }
+        }
+        s[t] = key;
+    }
+    __syncthreads();
+    bitonic_sort_desc<kChunk, 256>(s);
+    for (int t = threadIdx.x; t < k; t += 256) out[(int64_t)blockIdx.x * k + t] = s[t];
+}
+
+__global__ void keys_from_sims_kernel(const float* __restrict__ sims, int64_t n, int64_t n_pad,
+                                      uint64_t* __restrict__ keys) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_pad) return;
+    keys[g] = g < n ? (((uint64_t)order_bits(sims[g]) << 32) | (uint64_t)(uint32_t)g) : 0ull;
+}
+
+__global__ void bitonic_global_step_kernel(uint64_t* __restrict__ keys, int64_t half, int64_t j, int64_t k) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= half) return;
+    const int64_t i = 2 * t - (t & (j - 1));
+    const int64_t l = i + j;
+    const bool desc = (i & k) == 0;
+    const uint64_t a = keys[i], b = keys[l];
+    if ((a < b) == desc) { keys[i] = b; keys[l] = a; }
+}
+
+__global__ void decode_kernel(const uint64_t* __restrict__ keys, int k_out,
+                              int64_t* __restrict__ idx_out, float* __restrict__ sim_out,
+                              int32_t* __restrict__ n_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && n_out) *n_out = k_out;
+    if (t >= k_out) return;
+    const uint64_t key = keys[t];
+    idx_out[t] = (int64_t)(key & 0xFFFFFFFFull);
+    sim_out[t] = order_bits_inverse((uint32_t)(key >> 32));
+}
+
+__global__ void copy_keys_kernel(const uint64_t* __restrict__ src, int n_src, uint64_t* __restrict__ dst, int k) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < k) dst[t] = t < n_src ? src[t] : 0ull;
+}
+
+// Merge n_shards x k shard-local keys (0-padded) into the global top-k.
+__global__ __launch_bounds__(256) void merge_keys_kernel(const uint64_t* __restrict__ keys, int n_shards, int k,
+                                                         const int64_t* __restrict__ row_offset,
+                                                         int64_t* __restrict__ idx_out,
+                                                         float* __restrict__ sim_out,
+                                                         int32_t* __restrict__ n_out) {
+    __shared__ uint64_t s[kChunk];
+    __shared__ int n_valid;
+    if (threadIdx.x == 0) n_valid = 0;
+    __syncthreads();
+    const int total = n_shards * k;
+    int mine = 0;
+    for (int t = threadIdx.x; t < kChunk; t += 256) {
+        uint64_t key = 0;
+        if (t < total) {
+            key = keys[t];
+            if (key != 0) {
+                const uint64_t row = (key & 0xFFFFFFFFull) + (uint64_t)row_offset[t / k];
+                key = (key & 0xFFFFFFFF00000000ull) | (row & 0xFFFFFFFFull);
+                ++mine;
+            }
+        }
+        s[t] = key;
+    }
+    atomicAdd(&n_valid, mine);
+    __syncthreads();
+    bitonic_sort_desc<kChunk, 256>(s);
+    const int k_out = n_valid < k ? n_valid : k;
+    if (threadIdx.x == 0) *n_out = k_out;
+    for (int t = threadIdx.x; t < k_out; t += 256) {
+        idx_out[t] = (int64_t)(s[t] & 0xFFFFFFFFull);
+        sim_out[t] = order_bits_inverse((uint32_t)(s[t] >> 32));
+    }
+}
+
+struct ScanPlan {
+    int64_t n; int k_eff; bool full_sort; int64_t n_pad;
+    size_t off_sims, off_a, off_b, total;
+};
+
+static int64_t next_pow2(int64_t x) { int64_t p = 1; while (p < x) p <<= 1; return p; }
+
+static ScanPlan make_plan(int64_t n, int k) {
+    ScanPlan p{};
+    p.n = n;
+    p.k_eff = (int)((int64_t)k < n ? k : n);
+    p.full_sort = (n > kChunk) && (p.k_eff > kFastK);
+    p.n_pad = p.full_sort ? next_pow2(n) : 0;
+    size_t sims = align_up((size_t)(n > 0 ? n : 1) * sizeof(float), 256);
+    size_t a, b;
+    if (p.full_sort) {
+        a = (size_t)p.n_pad * 8; b = 0;
+    } else {
+        int64_t blocks1 = (n + kChunk - 1) / kChunk;
+        int64_t kk = p.k_eff > 0 ? p.k_eff : 1;
+        a = (size_t)blocks1 * kk * 8;
+        int64_t blocks2 = (blocks1 * kk + kChunk - 1) / kChunk;
+        b = (size_t)blocks2 * kk * 8;
+    }
+    p.off_sims = 0;
+    p.off_a = sims;
+    p.off_b = p.off_a + align_up(a, 256);
+    p.total = p.off_b + align_up(b, 256) + 256;
+    return p;
+}
+
+// Runs scan + selection; returns pointer (device) to the sorted best keys (>= k_eff entries).
+static int run_scan(const float* store, int64_t n, int dim, const float* query, int k,
+                    void* ws, size_t ws_bytes, hipStream_t st, const uint64_t** best, int* k_eff) {
+    HMM_REQUIRE(dim == HMM_FEATURE_DIM, HMM_E_INVALID, "cosine_topk: dim must be %d, got %d", HMM_FEATURE_DIM, dim);
+    HMM_REQUIRE(n >= 1 && n < (int64_t)0xFFFFFFFFll, HMM_E_INVALID, "cosine_topk: n_rows=%lld out of range", (long long)n);
+    HMM_REQUIRE(k >= 1, HMM_E_INVALID, "cosine_topk: k must be >= 1, got %d", k);
+    HMM_REQUIRE(store && query && ws, HMM_E_INVALID, "cosine_topk: null pointer");
+    HMM_REQUIRE(((uintptr_t)store & 15) == 0 && ((uintptr_t)query & 15) == 0, HMM_E_INVALID,
+                "cosine_topk: store/query must be 16-byte aligned");
+    const ScanPlan p = make_plan(n, k);
+    HMM_REQUIRE(ws_bytes >= p.total, HMM_E_WORKSPACE, "cosine_topk: workspace %zu < required %zu", ws_bytes, p.total);
+    char* base = static_cast<char*>(ws);
+    float* sims = reinterpret_cast<float*>(base + p.off_sims);
+    uint64_t* buf_a = reinterpret_cast<uint64_t*>(base + p.off_a);
+    uint64_t* buf_b = reinterpret_cast<uint64_t*>(base + p.off_b);
+
+    int64_t waves_needed = (n + 1) / 2;
+    int blocks = (int)((waves_needed + 3) / 4);
+    if (blocks > kScanBlocks) blocks = kScanBlocks;
+    scan_sims_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n,
+                                                   reinterpret_cast<const float4*>(query), sims);
+    HMM_LAUNCH_CHECK();
+
+    *k_eff = p.k_eff;
+    if (p.full_sort) {
+        const int64_t np = p.n_pad;
+        keys_from_sims_kernel<<<(unsigned)((np + 255) / 256), 256, 0, st>>>(sims, n, np, buf_a);
+        HMM_LAUNCH_CHECK();
+        const int64_t half = np / 2;
+        for (int64_t kk = 2; kk <= np; kk <<= 1)
+            for (int64_t j = kk >> 1; j > 0; j >>= 1)
+                bitonic_global_step_kernel<<<(unsigned)((half + 255) / 256), 256, 0, st>>>(buf_a, half, j, kk);
+        HMM_LAUNCH_CHECK();
+        *best = buf_a;
+        return HMM_OK;
+    }
+    int64_t count = n;
+    int64_t nblk = (count + kChunk - 1) / kChunk;
+    topk_chunk_kernel<true><<<(unsigned)nblk, 256, 0, st>>>(sims, count, p.k_eff, buf_a);
+    HMM_LAUNCH_CHECK();
+    uint64_t* cur = buf_a;
+    uint64_t* nxt = buf_b;
+    while (nblk > 1) {
+        count = nblk * p.k_eff;
+        nblk = (count + kChunk - 1) / kChunk;
+        topk_chunk_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(cur, count, p.k_eff, nxt);
+        HMM_LAUNCH_CHECK();
+        uint64_t* t = cur; cur = nxt; nxt = t;
+    }
+    *best = cur;
+    return HMM_OK;
+}
+
+}  // namespace hmm
+
+using namespace hmm;
+
+extern "C" size_t hmm_cosine_topk_workspace_bytes(int64_t n_rows, int k) {
+    if (n_rows < 1 || k < 1) return 0;
+    return make_plan(n_rows, k).total;
+}
+
+extern "C" int hmm_cosine_topk(const float* store_dev, int64_t n_rows, int dim, const float* query_dev, int k,
+                               int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
+                               void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream) {
+    HMM_REQUIRE(idx_out_dev && sim_out_dev, HMM_E_INVALID, "cosine_topk: null output pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint64_t* best = nullptr;
+    int k_eff = 0;
+    int rc = run_scan(store_dev, n_rows, dim, query_dev, k, workspace_dev, workspace_bytes, st, &best, &k_eff);
+    if (rc != HMM_OK) return rc;
+    decode_kernel<<<(k_eff + 255) / 256, 256, 0, st>>>(best, k_eff, idx_out_dev, sim_out_dev, n_out_dev);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+
+extern "C" int hmm_cosine_topk_keys(const float* store_dev, int64_t n_rows, int dim, const float* query_dev, int k,
+                                    uint64_t* keys_out_dev, void* workspace_dev, size_t workspace_bytes,
+                                    hmm_stream_t stream) {
+    HMM_REQUIRE(keys_out_dev, HMM_E_INVALID, "cosine_topk_keys: null output pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint64_t* best = nullptr;
+    int k_eff = 0;
+    int rc = run_scan(store_dev, n_rows, dim, query_dev, k, workspace_dev, workspace_bytes, st, &best, &k_eff);
+    if (rc != HMM_OK) return rc;
+    copy_keys_kernel<<<(k + 255) / 256, 256, 0, st>>>(best, k_eff, keys_out_dev, k);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+
+extern "C" int hmm_topk_merge_keys(const uint64_t* keys_dev, int n_shards, int k,
+                                   const int64_t* shard_row_offset_dev,
+                                   int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
+                                   hmm_stream_t stream) {
+    HMM_REQUIRE(keys_dev && shard_row_offset_dev && idx_out_dev && sim_out_dev && n_out_dev, HMM_E_INVALID,
+                "topk_merge_keys: null pointer");
+    HMM_REQUIRE(n_shards >= 1 && k >= 1 && (int64_t)n_shards * k <= kChunk, HMM_E_INVALID,
+                "topk_merge_keys: n_shards*k = %lld exceeds %d", (long long)n_shards * k, kChunk);
+    merge_keys_kernel<<<1, 256, 0, static_cast<hipStream_t>(stream)>>>(keys_dev, n_shards, k, shard_row_offset_dev,
+                                                                       idx_out_dev, sim_out_dev, n_out_dev);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}

@@ -1,0 +1,78 @@
+// Internal helpers shared by the gfx950 kernels of libhippomm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/hippomm_hip.h"
+
+namespace hmm {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kNumCU = 256;        // MI355X
+constexpr int kNumXCD = 8;
+
+void set_error(const char* fmt, ...);
+
+#define HMM_REQUIRE(cond, code, ...)                                   \
+    do {                                                               \
+        if (!(cond)) {                                                 \
+            ::hmm::set_error(__VA_ARGS__);                             \
+            return (code);                                             \
+        }                                                              \
+    } while (0)
+
+#define HMM_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ::hmm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                             __FILE__, __LINE__);                                        \
+            return HMM_E_HIP;                                                            \
+        }                                                                                \
+    } while (0)
+
+#define HMM_LAUNCH_CHECK() HMM_HIP_CHECK(hipGetLastError())
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- bf16 ------------------------------------------------------------------------------
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// ---- wave reductions (64 lanes) ----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// ---- total order used by the scan (see include/hippomm_hip.h) ------------------------------
+// monotone float -> uint32 map; NaN -> 0xFFFFFFFF (ranks first), -0.0 -> +0.0.
+__device__ __forceinline__ uint32_t order_bits(float s) {
+    if (s != s) return 0xFFFFFFFFu;
+    s += 0.0f;
+    uint32_t b = __float_as_uint(s);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float order_bits_inverse(uint32_t m) {
+    if (m == 0xFFFFFFFFu) return __uint_as_float(0x7FC00000u);
+    uint32_t b = (m & 0x80000000u) ? (m & 0x7FFFFFFFu) : ~m;
+    return __uint_as_float(b);
+}
+
+}  // namespace hmm

@@ -1,0 +1,134 @@
+"""feature_search scan on MI355X -- host-side mirror of hippomm/utils/vector_ops.py.
+
+``top_k_cosine_similarity(a, b, k)`` keeps the reference signature and return types
+(vector_ops.py:151-188) and runs on the HIP kernels behind ``hmm_cosine_topk``.
+
+The reference re-reads ``event.features[...]`` from host memory on every query
+(hippocampal_memory.py:3153, :3304).  To keep the store resident in HBM between queries wrap
+it once in a :class:`FeatureStore` (or pass a CUDA tensor); a numpy ``b`` is uploaded on every
+call, which is correct but PCIe-bound.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+
+FEATURE_DIM = 1024
+
+
+class FeatureStore:
+    """(N,1024) fp32 feature matrix resident in HBM (the ``memory_store`` vision/audio matrix
+    of one event, or many events concatenated), plus the scan workspace."""
+
+    def __init__(self, rows: Union[np.ndarray, torch.Tensor], device=None):
+        dev = device or _lib.require_gpu()
+        if isinstance(rows, np.ndarray):
+            self.source_dtype = rows.dtype
+            host = np.ascontiguousarray(rows.reshape(1, -1) if rows.ndim == 1 else rows, dtype=np.float32)
+            t = torch.from_numpy(host).to(dev)
+        else:
+            self.source_dtype = np.dtype(str(rows.dtype).replace("torch.", "")) if rows.dtype in (
+                torch.float32, torch.float64) else np.dtype(np.float32)
+            t = rows.reshape(1, -1) if rows.dim() == 1 else rows
+            t = t.to(device=dev, dtype=torch.float32).contiguous()
+        if t.dim() != 2 or t.shape[1] != FEATURE_DIM:
+            raise ValueError(f"store must be (N,{FEATURE_DIM}), got {tuple(t.shape)}")
+        self.rows = t
+        self._ws = None
+        self._ws_key = None
+
+    def __len__(self):
+        return self.rows.shape[0]
+
+    def _workspace(self, k: int):
+        lib = _lib.load()
+        need = lib.hmm_cosine_topk_workspace_bytes(len(self), k)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.rows.device)
+        return self._ws
+
+    def search_device(self, query: torch.Tensor, k: int):
+        """query: (1024,) fp32 CUDA tensor.  Returns CUDA tensors (idx int64[k'], sims fp32[k'])
+        without synchronising (k' = min(k, N))."""
+        lib = _lib.load()
+        n = len(self)
+        if k < 1:
+            raise ValueError("k must be >= 1")
+        k_out = min(k, n)
+        ws = self._workspace(k)
+        idx = torch.empty(k_out, dtype=torch.int64, device=self.rows.device)
+        sims = torch.empty(k_out, dtype=torch.float32, device=self.rows.device)
+        n_out = torch.empty(1, dtype=torch.int32, device=self.rows.device)
+        _lib.check(lib.hmm_cosine_topk(self.rows.data_ptr(), n, FEATURE_DIM, query.data_ptr(), k,
+                                       idx.data_ptr(), sims.data_ptr(), n_out.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+                   "hmm_cosine_topk")
+        return idx, sims
+
+    def search_keys_device(self, query: torch.Tensor, k: int) -> torch.Tensor:
+        """Local top-k as packed order keys (uint64 bit patterns in an int64 tensor, 0-padded to k)
+        for the sharded scan (hippomm_amd.sharding.sharded_top_k)."""
+        lib = _lib.load()
+        ws = self._workspace(k)
+        keys = torch.empty(k, dtype=torch.int64, device=self.rows.device)
+        _lib.check(lib.hmm_cosine_topk_keys(self.rows.data_ptr(), len(self), FEATURE_DIM, query.data_ptr(), k,
+                                            keys.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+                   "hmm_cosine_topk_keys")
+        return keys
+
+    def search(self, query, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        q = _query_to_device(query, self.rows.device)
+        idx, sims = self.search_device(q, k)
+        return idx.cpu().numpy(), sims.cpu().numpy()
+
+
+def merge_keys_device(keys: torch.Tensor, row_offsets: torch.Tensor, k: int):
+    """keys: (n_shards, k) int64 CUDA (packed order keys); row_offsets: (n_shards,) int64 CUDA."""
+    lib = _lib.load()
+    n_shards = keys.shape[0]
+    dev = keys.device
+    idx = torch.empty(k, dtype=torch.int64, device=dev)
+    sims = torch.empty(k, dtype=torch.float32, device=dev)
+    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.hmm_topk_merge_keys(keys.contiguous().data_ptr(), n_shards, k, row_offsets.data_ptr(),
+                                       idx.data_ptr(), sims.data_ptr(), n_out.data_ptr(), _lib.stream_ptr()),
+               "hmm_topk_merge_keys")
+    n = int(n_out.item())
+    return idx[:n], sims[:n]
+
+
+def _query_to_device(a, dev) -> torch.Tensor:
+    if isinstance(a, torch.Tensor):
+        q = a.detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+    else:
+        q = torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1), dtype=np.float32)).to(dev)
+    if q.numel() != FEATURE_DIM:
+        raise ValueError(f"query must have {FEATURE_DIM} elements, got {q.numel()}")
+    return q
+
+
+def top_k_cosine_similarity(
+    a: Union[np.ndarray, torch.Tensor],
+    b: Union[np.ndarray, torch.Tensor, FeatureStore],
+    k: int,
+) -> Tuple[np.ndarray, np.ndarray]:
+    """Top-k cosine similarities between one vector and many (reference vector_ops.py:151-188).
+
+    a: (1024,) query (numpy or torch); b: (N,1024) store (numpy, torch, or a resident
+    FeatureStore; a 1-D b is one row, as at :173-174).  Returns (indices int64[k'],
+    similarities[k']), k' = min(k, N), best first; similarities are float64 when either input was
+    float64 (numpy's promotion at :182) and float32 otherwise.  Ties: higher row index first;
+    a zero-norm row yields NaN and ranks first, as it does in the reference.
+    """
+    store = b if isinstance(b, FeatureStore) else FeatureStore(b)
+    a_is64 = (isinstance(a, np.ndarray) and a.dtype == np.float64) or (
+        isinstance(a, torch.Tensor) and a.dtype == torch.float64)
+    idx, sims = store.search(a, int(k))
+    if a_is64 or store.source_dtype == np.float64:
+        sims = sims.astype(np.float64)
+    return idx.astype(np.int64, copy=False), sims

@@ -1,0 +1,154 @@
+/*
+ * hippomm_hip.h -- C ABI of libhippomm_hip.so, the MI355X (gfx950) implementation of
+ * HippoMM's perceptual-encoding + similarity hot path.
+ *
+ * The reference (linyueqian/HippoMM) is pure Python and has no FFI; its boundary for this
+ * path is three Python call sites.  Each entry point below names the reference interface
+ * it replaces (file:line relative to the reference repo).  The Python shims that keep the
+ * reference signatures live in hippomm_amd/ (vector_ops.py, consolidation.py, encoder.py)
+ * and bind these symbols with ctypes; INTEGRATION.md shows the reference-side patch.
+ *
+ * Conventions
+ *   - plain C types only; every pointer named *_dev is a DEVICE pointer owned by the caller
+ *     (PyTorch-ROCm allocates).  The library never frees or reallocates caller memory and
+ *     never allocates outputs.  Only hmm_encoder_create() allocates (its own packed weights).
+ *   - every launch goes to the caller's stream (hipStream_t passed as void*); no call
+ *     synchronises the device, so all calls are graph-capturable.
+ *   - return value: 0 = ok, negative = error (HMM_E_*); hmm_last_error() returns a
+ *     thread-local message for the last failing call on this thread.
+ *   - single-threaded use per handle, as in the reference (all call sites are on the main
+ *     thread of one process).  Never call from a fork()ed child.
+ */
+#ifndef HIPPOMM_HIP_H
+#define HIPPOMM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMM_OK            0
+#define HMM_E_INVALID    -1   /* bad argument (shape, null pointer, unsupported size) */
+#define HMM_E_WORKSPACE  -2   /* workspace too small */
+#define HMM_E_HIP        -3   /* a HIP runtime call failed */
+#define HMM_E_STATE      -4   /* handle not ready (weights missing) */
+
+#define HMM_FEATURE_DIM  1024 /* width of every embedding / store row (reference shape guard:
+                                 hippocampal_memory.py:484, :829, :1190, :3135) */
+
+typedef void* hmm_stream_t;   /* hipStream_t */
+
+int         hmm_abi_version(void);
+const char* hmm_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * feature_search scan.  Replaces top_k_cosine_similarity(a, b, k)
+ * (hippomm/utils/vector_ops.py:151-188; callers hippocampal_memory.py:3153, :3304).
+ *
+ *   sims[i] = dot(store[i], q) / (||store[i]|| * ||q||)      fp32, one pass over the store
+ *   result  = the k' = min(k, n_rows) rows with the largest sims, best first.
+ *   Order on ties / NaN (the reference leaves these to numpy's argsort; this is what it was
+ *   observed to return): NaN (zero-norm row or query) ranks above every number; among equal
+ *   sims the HIGHER row index comes first; -0.0 == +0.0.
+ *
+ *   store_dev  (n_rows, 1024) fp32 row-major, resident in HBM      query_dev (1024) fp32
+ *   idx_out_dev int64[k'], sim_out_dev fp32[k'], n_out_dev int32[1] (= k')
+ * ---------------------------------------------------------------------------------------- */
+size_t hmm_cosine_topk_workspace_bytes(int64_t n_rows, int k);
+int    hmm_cosine_topk(const float* store_dev, int64_t n_rows, int dim,
+                       const float* query_dev, int k,
+                       int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
+                       void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
+
+/* Sharded scan: same scan, but emits the local top-k as packed 64-bit order keys
+ * ((ordered sim bits << 32) | local row) so that ranks can all-gather 8*k bytes and merge with
+ * hmm_topk_merge_keys, which adds each shard's row offset and applies the same total order. */
+int    hmm_cosine_topk_keys(const float* store_dev, int64_t n_rows, int dim,
+                            const float* query_dev, int k, uint64_t* keys_out_dev /* [k], 0-padded */,
+                            void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
+int    hmm_topk_merge_keys(const uint64_t* keys_dev /* [n_shards][k] */, int n_shards, int k,
+                           const int64_t* shard_row_offset_dev /* [n_shards] */,
+                           int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
+                           hmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Consolidation similarity.  Replaces HippocampalMemory._select_key_frames(features, times,
+ * similarity_threshold=0.9) (hippomm/core/hippocampal_memory.py:944-967; caller :855).
+ *
+ *   Fn = F / ||F||_rows (fp32), S = Fn Fn^T with every dot accumulated in fp64 (f64 MFMA) and
+ *   rounded to fp32 once, keep 0, then keep i iff all S[i, kept] < (float)threshold.
+ *   A NaN similarity blocks (as `nan < thr` is False in the reference).  n <= 2 keeps all.
+ *
+ *   features_dev (n, 1024) fp32 row-major   kept_out_dev int64[n] (first *n_kept valid)
+ * ---------------------------------------------------------------------------------------- */
+size_t hmm_gram_select_workspace_bytes(int n);
+int    hmm_gram_select(const float* features_dev, int n, int dim, float threshold,
+                       int64_t* kept_out_dev, int32_t* n_kept_out_dev,
+                       void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Perceptual encoder.  Replaces ImageBind._load_model / ImageBind.forward
+ * (hippomm/models/foundation_models.py:31-35, :116-133), i.e. upstream
+ * imagebind_huge's vision and audio towers (un-vendored third-party code; see
+ * oracle/imagebind_oracle.py for the restated architecture).
+ *
+ * One handle per tower.  bf16 MFMA GEMMs with fp32 accumulation, fp32 residual stream,
+ * fp32 LayerNorm / softmax statistics.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hmm_encoder hmm_encoder;
+
+#define HMM_TOWER_VISION 0   /* (B,3,224,224) fp32 -> (B,1024) unit rows                   */
+#define HMM_TOWER_AUDIO  1   /* (B,3,1,128,204) fp32 -> (B,1024) = mean_3clips(20 * unit)  */
+
+/* depth <= 0 selects the imagebind_huge depth (32 vision / 12 audio); a smaller depth builds
+ * the same tower with fewer blocks (used by CI-sized parity fixtures). */
+int  hmm_encoder_create(hmm_encoder** out, int tower, int depth);
+void hmm_encoder_destroy(hmm_encoder* enc);
+
+/* Upload one parameter by its UPSTREAM state-dict key (e.g.
+ * "modality_trunks.vision.blocks.7.attn.in_proj_weight").  data_dev is a DEVICE fp32 tensor
+ * with the upstream shape, contiguous; the library packs it (bf16 cast, Conv3d temporal-tap
+ * fold, ...) into its own storage on `stream`.  Unknown keys / wrong sizes fail. */
+int  hmm_encoder_load_param(hmm_encoder* enc, const char* upstream_key,
+                            const float* data_dev, int64_t numel, hmm_stream_t stream);
+/* Number of parameters still missing (0 = ready); names via hmm_last_error() when > 0. */
+int  hmm_encoder_missing_params(hmm_encoder* enc);
+
+size_t hmm_encoder_workspace_bytes(const hmm_encoder* enc, int batch);
+/* input_dev: vision (batch,3,224,224) fp32 | audio (batch,3,1,128,204) fp32
+ * out_dev:   (batch,1024) fp32 */
+int  hmm_encoder_forward(hmm_encoder* enc, const float* input_dev, int batch, float* out_dev,
+                         void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
+/* FLOPs (2 x MAC) one forward of `batch` samples performs, for roofline accounting. */
+double hmm_encoder_flops(const hmm_encoder* enc, int batch);
+
+/* ------------------------------------------------------------------------------------------
+ * Building blocks of the encoder, exported so that each kernel is parity-tested on its own
+ * against a torch fp32 reference of the same op (tests/test_gpu_ops.py) and timed on its own
+ * (bench.py roofline).  bf16 tensors are raw uint16 bit patterns in device memory.
+ * ---------------------------------------------------------------------------------------- */
+#define HMM_EPI_BIAS_BF16        0  /* C_bf16 = A W^T + bias                                  */
+#define HMM_EPI_BIAS_GELU_BF16   1  /* C_bf16 = gelu_erf(A W^T + bias)                        */
+#define HMM_EPI_BIAS_RESID_F32   2  /* C_f32 += A W^T + bias  (in-place residual)             */
+#define HMM_EPI_F32              3  /* C_f32 = A W^T (+ bias if non-null)                     */
+
+/* C[M,N] = A[M,K] (bf16 row-major, lda=K) x W[N,K]^T (bf16 row-major) ; K % 64 == 0, N % 128 == 0.
+ * Rows of A beyond M are never read; rows of C beyond M are never written. */
+int hmm_op_gemm_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
+                     void* c_dev, int M, int N, int K, int epilogue, hmm_stream_t stream);
+/* y_bf16[rows, D] = LayerNorm(x_f32[rows, D]) * gamma + beta ; D in {768, 1280} */
+int hmm_op_layernorm_bf16(const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                          uint16_t* y_dev, int rows, int D, float eps, hmm_stream_t stream);
+/* Multi-head self-attention core on packed qkv (rows = batch*tokens, 3*D columns ordered
+ * [q | k | v], heads contiguous inside each): out[rows, D] bf16.  bias_k/bias_v (D fp32, may be
+ * null) append one extra key/value position (nn.MultiheadAttention add_bias_kv). */
+int hmm_op_attention_bf16(const uint16_t* qkv_dev, uint16_t* out_dev, int batch, int tokens,
+                          int heads, int head_dim, const float* bias_k_dev, const float* bias_v_dev,
+                          hmm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPPOMM_HIP_H */
