@@ -1,0 +1,288 @@
+// ImageBind-huge vision / audio tower forward on gfx950: parameter packing by UPSTREAM state-dict
+// key, workspace plan and the kernel chain.  Replaces ImageBind._load_model / ImageBind.forward
+// (reference hippomm/models/foundation_models.py:31-35, :116-133), i.e. upstream
+// ImageBindModel.forward for the 'vision' and 'audio' keys (architecture restated in
+// oracle/imagebind_oracle.py).
+//
+// Per block (all on the caller's stream, no host sync, graph-capturable):
+//   LN1 (fp32 -> bf16)            layernorm_bf16_kernel
+//   QKV   [R,D]x[3D,D]^T + b      gemm_bf16 (EPI_BIAS_BF16)
+//   attention core                attention_kernel
+//   out-proj + b + residual       gemm_bf16 (EPI_BIAS_RESID_F32, in place on the fp32 stream)
+//   LN2                           layernorm_bf16_kernel
+//   fc1 + b + GELU(erf)           gemm_bf16 (EPI_BIAS_GELU_BF16)
+//   fc2 + b + residual            gemm_bf16 (EPI_BIAS_RESID_F32)
+// HBM layout (workspace, R = images*tokens rows): residual stream x fp32 [R][D]; one bf16 [R][D]
+// buffer shared by the LN output and the attention output; one bf16 [R][4D] buffer shared by qkv
+// ([R][3D]) and the MLP hidden ([R][4D]) -- the patch im2col matrix and the patch-projection output
+// alias it too, since they are dead before block 0.
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "hmm_common.h"
+#include "encoder_ops.h"
+
+namespace hmm {
+
+enum PackKind { PACK_F32, PACK_BF16, PACK_FOLD_CONV3D };
+
+struct ParamSlot {
+    size_t offset;      // bytes into the arena
+    int64_t numel_src;  // elements the caller must provide
+    PackKind kind;
+    bool loaded;
+};
+
+struct BlockW {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *qkv_b, *out_b, *fc1_b, *fc2_b, *bias_k, *bias_v;
+    bf16_t *qkv_w, *out_w, *fc1_w, *fc2_w;
+};
+
+}  // namespace hmm
+
+using namespace hmm;
+
+struct hmm_encoder {
+    int tower, D, depth, heads, mlp, n_patches, T, patch_k, patch_k_pad, clips;
+    bool pre_ln, stem_ln, bias_kv, scaled;
+    bool ready = false;
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    std::unordered_map<std::string, ParamSlot> slots;
+    // resolved pointers
+    float *cls, *pos, *stem_g, *stem_b, *pre_g, *pre_b, *head_g, *head_b, *log_scale;
+    bf16_t *patch_w, *head_w;
+    std::vector<BlockW> blocks;
+};
+
+namespace hmm {
+
+struct ArenaBuilder {
+    hmm_encoder* e;
+    size_t cursor = 0;
+    size_t add(const std::string& key, int64_t numel_src, PackKind kind, size_t bytes_dst) {
+        const size_t off = cursor;
+        e->slots[key] = ParamSlot{off, numel_src, kind, false};
+        cursor = align_up(cursor + bytes_dst, 256);
+        return off;
+    }
+};
+
+static void plan_params(hmm_encoder* e, std::vector<std::pair<void**, size_t>>& fix) {
+    ArenaBuilder ab{e};
+    const std::string m = e->tower == HMM_TOWER_VISION ? "vision" : "audio";
+    const std::string pp = "modality_preprocessors." + m + ".";
+    const std::string tr = "modality_trunks." + m + ".";
+    const std::string hd = "modality_heads." + m + ".";
+    const int D = e->D;
+    auto f32 = [&](const std::string& key, int64_t n, float** dst) {
+        fix.push_back({reinterpret_cast<void**>(dst), ab.add(key, n, PACK_F32, (size_t)n * 4)});
+    };
+    auto b16 = [&](const std::string& key, int64_t n, bf16_t** dst) {
+        fix.push_back({reinterpret_cast<void**>(dst), ab.add(key, n, PACK_BF16, (size_t)n * 2)});
+    };
+    f32(pp + "cls_token", D, &e->cls);
+    f32(pp + "pos_embedding_helper.pos_embed", (int64_t)e->T * D, &e->pos);
+    if (e->tower == HMM_TOWER_VISION) {
+        fix.push_back({reinterpret_cast<void**>(&e->patch_w),
+                       ab.add(pp + "rgbt_stem.proj.1.weight", (int64_t)D * 3 * 2 * 14 * 14, PACK_FOLD_CONV3D,
+                              (size_t)D * e->patch_k_pad * 2)});
+    } else {
+        b16(pp + "rgbt_stem.proj.weight", (int64_t)D * 256, &e->patch_w);
+        f32(pp + "rgbt_stem.norm_layer.weight", D, &e->stem_g);
+        f32(pp + "rgbt_stem.norm_layer.bias", D, &e->stem_b);
+    }
+    if (e->pre_ln) {
+        f32(tr + "pre_transformer_layer.0.weight", D, &e->pre_g);
+        f32(tr + "pre_transformer_layer.0.bias", D, &e->pre_b);
+    }
+    e->blocks.resize(e->depth);
+    for (int i = 0; i < e->depth; ++i) {
+        const std::string b = tr + "blocks." + std::to_string(i) + ".";
+        BlockW& w = e->blocks[i];
+        f32(b + "norm_1.weight", D, &w.ln1_g);
+        f32(b + "norm_1.bias", D, &w.ln1_b);
+        b16(b + "attn.in_proj_weight", (int64_t)3 * D * D, &w.qkv_w);
+        f32(b + "attn.in_proj_bias", 3 * D, &w.qkv_b);
+        if (e->bias_kv) {
+            f32(b + "attn.bias_k", D, &w.bias_k);
+            f32(b + "attn.bias_v", D, &w.bias_v);
+        } else {
+            w.bias_k = w.bias_v = nullptr;
+        }
+        b16(b + "attn.out_proj.weight", (int64_t)D * D, &w.out_w);
+        f32(b + "attn.out_proj.bias", D, &w.out_b);
+        f32(b + "norm_2.weight", D, &w.ln2_g);
+        f32(b + "norm_2.bias", D, &w.ln2_b);
+        b16(b + "mlp.fc1.weight", (int64_t)e->mlp * D, &w.fc1_w);
+        f32(b + "mlp.fc1.bias", e->mlp, &w.fc1_b);
+        b16(b + "mlp.fc2.weight", (int64_t)D * e->mlp, &w.fc2_w);
+        f32(b + "mlp.fc2.bias", D, &w.fc2_b);
+    }
+    f32(hd + "0.weight", D, &e->head_g);
+    f32(hd + "0.bias", D, &e->head_b);
+    b16(hd + "2.weight", (int64_t)HMM_FEATURE_DIM * D, &e->head_w);
+    if (e->scaled) f32("modality_postprocessors.audio.1.log_logit_scale", 1, &e->log_scale);
+    e->arena_bytes = ab.cursor;
+}
+
+struct WsPlan { int n_img, R; size_t off_x, off_a, off_big, off_im2col, off_patch, off_hl, off_hv, total; };
+
+static WsPlan ws_plan(const hmm_encoder* e, int batch) {
+    WsPlan p{};
+    p.n_img = batch * e->clips;
+    p.R = p.n_img * e->T;
+    const size_t D = e->D;
+    size_t cur = 0;
+    p.off_x = cur;   cur = align_up(cur + (size_t)p.R * D * 4, 256);
+    p.off_a = cur;   cur = align_up(cur + (size_t)p.R * D * 2, 256);
+    p.off_big = cur;
+    const size_t big = (size_t)p.R * e->mlp * 2;
+    p.off_im2col = p.off_big;
+    const size_t im2col = align_up((size_t)p.n_img * e->n_patches * e->patch_k_pad * 2, 256);
+    p.off_patch = p.off_big + im2col;
+    const size_t pre = im2col + (size_t)p.n_img * e->n_patches * D * 4;
+    cur = align_up(cur + (big > pre ? big : pre), 256);
+    p.off_hl = cur;  cur = align_up(cur + (size_t)p.n_img * D * 2, 256);
+    p.off_hv = cur;  cur = align_up(cur + (size_t)p.n_img * HMM_FEATURE_DIM * 4, 256);
+    p.total = cur + 256;
+    return p;
+}
+
+}  // namespace hmm
+
+extern "C" int hmm_encoder_create(hmm_encoder** out, int tower, int depth) {
+    HMM_REQUIRE(out, HMM_E_INVALID, "encoder_create: null out");
+    HMM_REQUIRE(tower == HMM_TOWER_VISION || tower == HMM_TOWER_AUDIO, HMM_E_INVALID, "encoder_create: tower %d", tower);
+    hmm_encoder* e = new hmm_encoder();
+    e->tower = tower;
+    if (tower == HMM_TOWER_VISION) {
+        e->D = 1280; e->depth = 32; e->heads = 16; e->mlp = 5120; e->n_patches = 256;
+        e->patch_k = 588; e->patch_k_pad = 640; e->clips = 1;
+        e->pre_ln = true; e->stem_ln = false; e->bias_kv = false; e->scaled = false;
+    } else {
+        e->D = 768; e->depth = 12; e->heads = 12; e->mlp = 3072; e->n_patches = 228;
+        e->patch_k = 256; e->patch_k_pad = 256; e->clips = 3;
+        e->pre_ln = false; e->stem_ln = true; e->bias_kv = true; e->scaled = true;
+    }
+    if (depth > 0) e->depth = depth;
+    e->T = e->n_patches + 1;
+    e->cls = e->pos = e->stem_g = e->stem_b = e->pre_g = e->pre_b = e->head_g = e->head_b = e->log_scale = nullptr;
+    e->patch_w = e->head_w = nullptr;
+    std::vector<std::pair<void**, size_t>> fix;
+    plan_params(e, fix);
+    hipError_t err = hipMalloc(reinterpret_cast<void**>(&e->arena), e->arena_bytes);
+    if (err != hipSuccess) {
+        set_error("encoder_create: hipMalloc(%zu) failed: %s", e->arena_bytes, hipGetErrorString(err));
+        delete e;
+        return HMM_E_HIP;
+    }
+    for (auto& f : fix) *f.first = e->arena + f.second;
+    *out = e;
+    return HMM_OK;
+}
+
+extern "C" void hmm_encoder_destroy(hmm_encoder* e) {
+    if (!e) return;
+    if (e->arena) (void)hipFree(e->arena);
+    delete e;
+}
+
+extern "C" int hmm_encoder_load_param(hmm_encoder* e, const char* key, const float* data_dev, int64_t numel,
+                                      hmm_stream_t stream) {
+    HMM_REQUIRE(e && key && data_dev, HMM_E_INVALID, "encoder_load_param: null argument");
+    auto it = e->slots.find(key);
+    HMM_REQUIRE(it != e->slots.end(), HMM_E_INVALID, "encoder_load_param: unexpected key '%s'", key);
+    ParamSlot& s = it->second;
+    HMM_REQUIRE(numel == s.numel_src, HMM_E_INVALID, "encoder_load_param: '%s' has %lld elements, expected %lld", key,
+                (long long)numel, (long long)s.numel_src);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* dst = e->arena + s.offset;
+    int rc = HMM_OK;
+    switch (s.kind) {
+        case PACK_F32:  rc = launch_copy_f32(data_dev, reinterpret_cast<float*>(dst), numel, st); break;
+        case PACK_BF16: rc = launch_cast_bf16(data_dev, reinterpret_cast<bf16_t*>(dst), numel, st); break;
+        case PACK_FOLD_CONV3D: rc = launch_fold_conv3d(data_dev, reinterpret_cast<bf16_t*>(dst), e->D, st); break;
+    }
+    if (rc == HMM_OK) s.loaded = true;
+    return rc;
+}
+
+extern "C" int hmm_encoder_missing_params(hmm_encoder* e) {
+    if (!e) return -1;
+    int missing = 0;
+    std::string names;
+    for (auto& kv : e->slots)
+        if (!kv.second.loaded) {
+            if (missing < 8) names += (missing ? ", " : "") + kv.first;
+            ++missing;
+        }
+    if (missing) set_error("%d parameter(s) not loaded: %s%s", missing, names.c_str(), missing > 8 ? ", ..." : "");
+    return missing;
+}
+
+extern "C" size_t hmm_encoder_workspace_bytes(const hmm_encoder* e, int batch) {
+    if (!e || batch < 1) return 0;
+    return ws_plan(e, batch).total;
+}
+
+extern "C" double hmm_encoder_flops(const hmm_encoder* e, int batch) {
+    if (!e || batch < 1) return 0.0;
+    const double D = e->D, T = e->T, H = e->mlp, Lk = e->T + (e->bias_kv ? 1 : 0);
+    // un-folded patch projection, as the reference computes it (vision: both temporal taps)
+    const double patch_k = e->tower == HMM_TOWER_VISION ? 2.0 * e->patch_k : e->patch_k;
+    double macs = e->n_patches * patch_k * D;                        // patch projection
+    macs += e->depth * (T * D * (3 * D + D + 2 * H) + 2 * T * Lk * D);   // projections + MLP + QK^T + PV
+    macs += D * HMM_FEATURE_DIM;                                     // head
+    return 2.0 * macs * batch * e->clips;
+}
+
+extern "C" int hmm_encoder_forward(hmm_encoder* e, const float* input_dev, int batch, float* out_dev,
+                                   void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream) {
+    HMM_REQUIRE(e && input_dev && out_dev && workspace_dev, HMM_E_INVALID, "encoder_forward: null argument");
+    HMM_REQUIRE(batch >= 1, HMM_E_INVALID, "encoder_forward: batch=%d", batch);
+    if (!e->ready) {
+        HMM_REQUIRE(hmm_encoder_missing_params(e) == 0, HMM_E_STATE, "encoder_forward: %s", hmm_last_error());
+        e->ready = true;
+    }
+    const WsPlan p = ws_plan(e, batch);
+    HMM_REQUIRE((int64_t)p.n_img * e->T < (1ll << 31) / 8, HMM_E_INVALID, "encoder_forward: batch too large");
+    HMM_REQUIRE(workspace_bytes >= p.total, HMM_E_WORKSPACE, "encoder_forward: workspace %zu < required %zu",
+                workspace_bytes, p.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace_dev);
+    float* x = reinterpret_cast<float*>(ws + p.off_x);
+    bf16_t* a = reinterpret_cast<bf16_t*>(ws + p.off_a);
+    bf16_t* big = reinterpret_cast<bf16_t*>(ws + p.off_big);
+    bf16_t* im2col = reinterpret_cast<bf16_t*>(ws + p.off_im2col);
+    float* patch = reinterpret_cast<float*>(ws + p.off_patch);
+    bf16_t* hl = reinterpret_cast<bf16_t*>(ws + p.off_hl);
+    float* hv = reinterpret_cast<float*>(ws + p.off_hv);
+    const int D = e->D, T = e->T, R = p.R, n_img = p.n_img;
+    int rc;
+#define HMM_TRY(call) do { rc = (call); if (rc != HMM_OK) return rc; } while (0)
+
+    // patchify -> tokens
+    if (e->tower == HMM_TOWER_VISION) HMM_TRY(launch_im2col_vision(input_dev, im2col, n_img, st));
+    else                              HMM_TRY(launch_im2col_audio(input_dev, im2col, n_img, st));
+    HMM_TRY(gemm_bf16(im2col, e->patch_w, nullptr, patch, n_img * e->n_patches, D, e->patch_k_pad, HMM_EPI_F32, -1, st));
+    HMM_TRY(launch_assemble_tokens(patch, e->cls, e->pos, e->stem_g, e->stem_b, 1e-5f, e->pre_g, e->pre_b, 1e-6f,
+                                   x, n_img, T, D, st));
+    // transformer blocks
+    for (int i = 0; i < e->depth; ++i) {
+        const BlockW& w = e->blocks[i];
+        HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
+        HMM_TRY(gemm_bf16(a, w.qkv_w, w.qkv_b, big, R, 3 * D, D, HMM_EPI_BIAS_BF16, -1, st));
+        HMM_TRY(attention_bf16(big, a, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st));
+        HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, -1, st));
+        HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
+        HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, -1, st));
+        HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, -1, st));
+    }
+    // head: LN on the cls rows -> Linear(D,1024) -> L2 normalise (x20, clip mean for audio)
+    HMM_TRY(launch_layernorm_bf16(x, (size_t)T * D, e->head_g, e->head_b, hl, n_img, D, 1e-6f, st));
+    HMM_TRY(gemm_bf16(hl, e->head_w, nullptr, hv, n_img, HMM_FEATURE_DIM, D, HMM_EPI_F32, -1, st));
+    HMM_TRY(launch_l2norm_rows(hv, out_dev, batch, e->clips, e->log_scale, st));
+#undef HMM_TRY
+    return HMM_OK;
+}

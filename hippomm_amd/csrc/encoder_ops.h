@@ -1,0 +1,26 @@
+// Internal launchers shared between the encoder orchestration and the exported hmm_op_* entry points.
+#pragma once
+#include "hmm_common.h"
+
+namespace hmm {
+
+int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int epi,
+              int variant, hipStream_t st);
+
+int launch_layernorm_bf16(const float* x, size_t in_stride, const float* g, const float* b, bf16_t* y,
+                          int rows, int D, float eps, hipStream_t st);
+int launch_assemble_tokens(const float* patches, const float* cls, const float* pos,
+                           const float* stem_g, const float* stem_b, float stem_eps,
+                           const float* pre_g, const float* pre_b, float pre_eps,
+                           float* x, int n_img, int T, int D, hipStream_t st);
+int launch_im2col_vision(const float* frames, bf16_t* out, int n_img, hipStream_t st);
+int launch_im2col_audio(const float* mels, bf16_t* out, int n_clip, hipStream_t st);
+int launch_l2norm_rows(const float* v, float* out, int n_out, int clips, const float* log_scale, hipStream_t st);
+int launch_cast_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t st);
+int launch_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);
+int launch_fold_conv3d(const float* w, bf16_t* dst, int D, hipStream_t st);
+
+int attention_bf16(const bf16_t* qkv, bf16_t* out, int batch, int tokens, int heads, int head_dim,
+                   const float* bias_k, const float* bias_v, hipStream_t st);
+
+}  // namespace hmm

@@ -1,0 +1,177 @@
+"""GPU parity of each encoder kernel on its own against a torch fp32 reference of the same op
+(computed on the CPU from the same bf16-rounded operands)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_RESID_F32, EPI_F32 = 0, 1, 2, 3
+BF16_EPS = 2.0 ** -8          # half an ulp of bf16, relative
+
+
+def _lib():
+    from hippomm_amd import _lib as L
+    lib = L.load()
+    if not hasattr(lib, "_dev_ready"):
+        lib.hmm_dev_gemm_bf16_variant.restype = C.c_int
+        lib.hmm_dev_gemm_bf16_variant.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
+        lib._dev_ready = True
+    return L, lib
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16)
+
+
+def _close_bf16(got, want, extra_atol=0.0):
+    """got is bf16-rounded output of an fp32-accumulated op; want is the fp32 reference."""
+    got, want = got.float().cpu(), want.float().cpu()
+    tol = BF16_EPS * want.abs() * 1.01 + 1e-5 * want.abs().max() + extra_atol
+    bad = (got - want).abs() > tol
+    assert not bad.any(), f"{int(bad.sum())} / {bad.numel()} off; worst {float((got - want).abs().max()):.4g}"
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(257, 1280, 1280), (514, 3840, 1280), (300, 5120, 1280), (257, 1280, 5120),
+                                   (1, 1024, 1280), (130, 768, 256), (512, 1280, 640), (1000, 2304, 768)])
+def test_gemm_bias_bf16(variant, M, N, K):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _bf16(torch.randn(M, K, generator=g))
+    w = _bf16(torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g)
+    want = a.float() @ w.float().T + bias
+    ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+    c = torch.full((M + 3, N), float("nan"), dtype=torch.bfloat16, device="cuda")   # canary rows past M
+    L.check(lib.hmm_dev_gemm_bf16_variant(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), c.data_ptr(), M, N, K,
+                                          EPI_BIAS_BF16, variant, L.stream_ptr()), "gemm")
+    _close_bf16(c[:M], want)
+    assert torch.isnan(c[M:].float()).all(), "rows past M were written"
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_gemm_gelu_resid_f32_epilogues(variant):
+    L, lib = _lib()
+    M, N, K = 771, 1280, 1280
+    g = torch.Generator().manual_seed(5)
+    a = _bf16(torch.randn(M, K, generator=g))
+    w = _bf16(torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g)
+    lin = a.float() @ w.float().T + bias
+    ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+    # GELU(erf)
+    c = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_dev_gemm_bf16_variant(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), c.data_ptr(), M, N, K,
+                                          EPI_BIAS_GELU_BF16, variant, L.stream_ptr()), "gemm gelu")
+    _close_bf16(c, F.gelu(lin), extra_atol=2e-5)
+    # fp32 residual, in place
+    x0 = torch.randn(M, N, generator=g)
+    x = x0.clone().cuda()
+    L.check(lib.hmm_dev_gemm_bf16_variant(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), x.data_ptr(), M, N, K,
+                                          EPI_BIAS_RESID_F32, variant, L.stream_ptr()), "gemm resid")
+    torch.testing.assert_close(x.cpu(), x0 + lin, rtol=2e-5, atol=2e-4)
+    # plain fp32, no bias
+    y = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    L.check(lib.hmm_dev_gemm_bf16_variant(ad.data_ptr(), wd.data_ptr(), None, y.data_ptr(), M, N, K,
+                                          EPI_F32, variant, L.stream_ptr()), "gemm f32")
+    torch.testing.assert_close(y.cpu(), lin - bias, rtol=2e-5, atol=2e-4)
+
+
+def test_gemm_identity_asymmetric():
+    """A = I against an asymmetric W catches a transposed / permuted accumulator mapping exactly."""
+    L, lib = _lib()
+    K = N = 256
+    a = torch.eye(K).to(torch.bfloat16)
+    w = (torch.arange(N * K).reshape(N, K) % 251 - 125).float().to(torch.bfloat16)   # exact in bf16
+    y = torch.empty(K, N, dtype=torch.float32, device="cuda")
+    for variant in (0, 1, 2):
+        y.zero_()
+        L.check(lib.hmm_dev_gemm_bf16_variant(a.cuda().data_ptr(), w.cuda().data_ptr(), None, y.data_ptr(), K, N, K,
+                                              EPI_F32, variant, L.stream_ptr()), "gemm")
+        assert torch.equal(y.cpu(), w.float().T)
+
+
+@pytest.mark.parametrize("rows,D", [(1, 768), (5, 1280), (1029, 1280), (700, 768)])
+def test_layernorm(rows, D):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(rows + D)
+    x = torch.randn(rows, D, generator=g) * 3 + 0.7
+    gamma, beta = 1 + 0.2 * torch.randn(D, generator=g), 0.3 * torch.randn(D, generator=g)
+    want = F.layer_norm(x, (D,), gamma, beta, 1e-6)
+    y = torch.empty(rows, D, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_layernorm_bf16(x.cuda().data_ptr(), gamma.cuda().data_ptr(), beta.cuda().data_ptr(),
+                                      y.data_ptr(), rows, D, 1e-6, L.stream_ptr()), "layernorm")
+    _close_bf16(y, want, extra_atol=1e-5)
+
+
+def _attention_ref(qkv, B, T, H, dh, bias_k=None, bias_v=None):
+    D = H * dh
+    q, k, v = qkv.float().reshape(B, T, 3, H, dh).unbind(2)          # (B,T,H,dh)
+    q, k, v = (t.permute(0, 2, 1, 3) for t in (q, k, v))             # (B,H,T,dh)
+    if bias_k is not None:
+        bk = bias_k.to(torch.bfloat16).float().reshape(1, H, 1, dh).expand(B, -1, -1, -1)
+        bv = bias_v.to(torch.bfloat16).float().reshape(1, H, 1, dh).expand(B, -1, -1, -1)
+        k, v = torch.cat([k, bk], 2), torch.cat([v, bv], 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    o = torch.softmax(s, dim=-1) @ v
+    return o.permute(0, 2, 1, 3).reshape(B * T, D)
+
+
+@pytest.mark.parametrize("B,T,H,dh,bias,scale", [(2, 257, 16, 80, False, 1.0), (3, 229, 12, 64, True, 1.0),
+                                                 (1, 257, 16, 80, False, 6.0), (2, 229, 12, 64, True, 6.0),
+                                                 (1, 40, 2, 80, False, 2.0), (1, 33, 3, 64, True, 2.0),
+                                                 (1, 1, 1, 64, False, 1.0)])
+def test_attention(B, T, H, dh, bias, scale):
+    """scale > 1 makes the softmax peaky so that masking / max / row-sum mistakes show."""
+    L, lib = _lib()
+    D = H * dh
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * scale).to(torch.bfloat16)
+    bk = torch.randn(D, generator=g) * scale if bias else None
+    bv = torch.randn(D, generator=g) * scale if bias else None
+    want = _attention_ref(qkv, B, T, H, dh, bk, bv)
+    out = torch.full((B * T, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_attention_bf16(qkv.cuda().data_ptr(), out.data_ptr(), B, T, H, dh,
+                                      bk.cuda().data_ptr() if bias else None,
+                                      bv.cuda().data_ptr() if bias else None, L.stream_ptr()), "attention")
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    # P is rounded to bf16 before P.V (as in every flash kernel): error <= 2^-9 * sum|p v| per element
+    tol = 2.0 ** -8 * want.abs() + 2.0 ** -8 * scale + 1e-4
+    bad = (got - want).abs() > tol
+    assert not bad.any(), f"{int(bad.sum())}/{bad.numel()} off; worst {float((got - want).abs().max()):.4g}"
+
+
+def test_attention_one_hot_rows_pick_the_right_value():
+    """Exact structural check.  Key j lies on axis j % dh with length 1 + j // dh; a query of length
+    300 along axis a therefore scores 300 * len / sqrt(dh) on that axis' keys and 0 elsewhere, so the
+    longest key of the axis wins by > 30 nats and the output row must be exactly that key's V row.
+    Covers the last (257th) key and the add_bias_kv position, which are the tops of their axes."""
+    L, lib = _lib()
+    for (T, H, dh, bias) in [(257, 16, 80, False), (229, 12, 64, True)]:
+        D, Lk = H * dh, T + (1 if bias else 0)
+        g = torch.Generator().manual_seed(T)
+        k = torch.zeros(Lk, H, dh)
+        for j in range(Lk):
+            k[j, :, j % dh] = 1.0 + j // dh
+        top = {j % dh: j for j in range(Lk)}                      # longest key per axis
+        v = torch.randn(Lk, H, dh, generator=g).to(torch.bfloat16).float()
+        axis = torch.arange(T) % dh
+        axis[0] = (Lk - 1) % dh                                   # query 0 -> the very last key
+        q = torch.zeros(T, H, dh)
+        q[torch.arange(T), :, axis] = 300.0
+        qkv = torch.zeros(T, 3, H, dh)
+        qkv[:, 0], qkv[:, 1], qkv[:, 2] = q, k[:T], v[:T]
+        bk = k[T].reshape(D).cuda() if bias else None
+        bv = v[T].reshape(D).cuda() if bias else None
+        out = torch.empty(T, D, dtype=torch.bfloat16, device="cuda")
+        L.check(lib.hmm_op_attention_bf16(qkv.reshape(T, 3 * D).to(torch.bfloat16).cuda().data_ptr(), out.data_ptr(),
+                                          1, T, H, dh, bk.data_ptr() if bias else None,
+                                          bv.data_ptr() if bias else None, L.stream_ptr()), "attention")
+        want = v[torch.tensor([top[int(a)] for a in axis])].reshape(T, D)
+        assert torch.equal(out.float().cpu(), want)

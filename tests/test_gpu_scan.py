@@ -17,6 +17,28 @@ GOLD = json.loads((Path(__file__).resolve().parent / "golden" / "scan_golden.jso
 SIM_ATOL = 2e-6          # fp32 scan vs the reference's fp32/fp64 numpy result
 
 
+def assert_topk_matches(idx, sims, store, q, k):
+    """Indices must equal the oracle's wherever the oracle's neighbouring similarities are
+    further apart than the fp32 tolerance (always the case for the reference's k=5 / cfg-4's
+    k=32 on these inputs); inside a run of near-equal values (only seen when ranking thousands
+    of rows) the fp32 scan may order them differently, so there the check is on values: the
+    row returned at rank i must have the oracle's rank-i similarity within tolerance."""
+    want_idx, want_sims = top_k_cosine_similarity_oracle(q, store, k)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        all_sims = (store @ q) / (np.linalg.norm(store, axis=1) * np.linalg.norm(q))
+    assert len(idx) == len(want_idx) and len(set(idx.tolist())) == len(idx)
+    np.testing.assert_allclose(sims, want_sims, rtol=0, atol=SIM_ATOL)
+    np.testing.assert_allclose(all_sims[idx], want_sims, rtol=0, atol=SIM_ATOL)
+    ordered = np.sort(all_sims)[::-1][: len(want_idx) + 1]
+    gaps = ordered[:-1] - ordered[1:]
+    separated = np.ones(len(want_idx), dtype=bool)
+    close = gaps <= 4 * SIM_ATOL
+    separated[close[: len(want_idx)]] = False           # rank i vs i+1
+    separated[1:][close[: len(want_idx) - 1]] = False   # rank i vs i-1
+    assert np.array_equal(idx[separated], want_idx[separated])
+    return int(separated.sum())
+
+
 def _sims(case):
     return np.array([np.nan if s is None else s for s in case["sims"]], dtype=np.float64)
 
@@ -41,10 +63,10 @@ def test_matches_oracle(n, k):
     rng = np.random.default_rng(n * 31 + k)
     store = rng.standard_normal((n, 1024), dtype=np.float32)
     q = rng.standard_normal(1024, dtype=np.float32)
-    want_idx, want_sims = top_k_cosine_similarity_oracle(q, store, k)
     idx, sims = top_k_cosine_similarity(q, store, k)
-    assert idx.tolist() == want_idx.tolist()
-    np.testing.assert_allclose(sims, want_sims, rtol=0, atol=SIM_ATOL)
+    n_exact = assert_topk_matches(idx, sims, store, q, k)
+    if k <= 1024:
+        assert n_exact == len(idx), "top-k on random rows must be index-exact"
 
 
 def test_accepts_torch_and_resident_store():
