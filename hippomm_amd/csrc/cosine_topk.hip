@@ -324,3 +324,15 @@ extern "C" int hmm_topk_merge_keys(const uint64_t* keys_dev, int n_shards, int k
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
+
+// Timing hook (not in the public header): the streaming kernel alone, for bench.py's roofline.
+extern "C" int hmm_dev_scan_sims(const float* store_dev, int64_t n_rows, const float* query_dev, float* sims_dev,
+                                 hmm_stream_t stream) {
+    int64_t waves_needed = (n_rows + 1) / 2;
+    int blocks = (int)((waves_needed + 3) / 4);
+    if (blocks > kScanBlocks) blocks = kScanBlocks;
+    scan_sims_kernel<true><<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
+        reinterpret_cast<const float4*>(store_dev), n_rows, reinterpret_cast<const float4*>(query_dev), sims_dev);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}

@@ -81,8 +81,13 @@ def reduced(spec: TowerSpec, depth: int) -> TowerSpec:
     return replace(spec, depth=depth)
 
 
+_FAST_INIT = False
+
+
 def _tn(gen, shape, std):
     t = torch.empty(shape, dtype=torch.float32)
+    if _FAST_INIT:                      # timing-only weights (bench cpu_baseline): plain normal
+        return t.normal_(0.0, std, generator=gen)
     torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=gen)
     return t
 
@@ -93,11 +98,14 @@ def synthetic_state(spec: TowerSpec, seed: int = 1234, init: str = "survey",
 
     init='survey': Linear/Conv/pos/cls trunc_normal(std), biases 0, LN gamma 1 beta 0
                    (cfg 1/2).
+    init='fast'  : as 'survey' with plain normal draws (quick to generate; timing-only).
     init='rich'  : additionally random biases, LN gamma/beta and bias_k/bias_v, so
                    that a dropped bias or affine term is visible in a parity test.
     """
+    global _FAST_INIT
     g = torch.Generator().manual_seed(seed)
     rich = init == "rich"
+    _FAST_INIT = init == "fast"
     D, m = spec.embed_dim, spec.name
     pp, tr, hd = f"modality_preprocessors.{m}.", f"modality_trunks.{m}.", f"modality_heads.{m}."
     st: Dict[str, torch.Tensor] = {}

@@ -89,9 +89,10 @@ def test_gemm_identity_asymmetric():
     a = torch.eye(K).to(torch.bfloat16)
     w = (torch.arange(N * K).reshape(N, K) % 251 - 125).float().to(torch.bfloat16)   # exact in bf16
     y = torch.empty(K, N, dtype=torch.float32, device="cuda")
+    ad, wd = a.cuda(), w.cuda()
     for variant in (0, 1, 2):
         y.zero_()
-        L.check(lib.hmm_dev_gemm_bf16_variant(a.cuda().data_ptr(), w.cuda().data_ptr(), None, y.data_ptr(), K, N, K,
+        L.check(lib.hmm_dev_gemm_bf16_variant(ad.data_ptr(), wd.data_ptr(), None, y.data_ptr(), K, N, K,
                                               EPI_F32, variant, L.stream_ptr()), "gemm")
         assert torch.equal(y.cpu(), w.float().T)
 
@@ -104,7 +105,8 @@ def test_layernorm(rows, D):
     gamma, beta = 1 + 0.2 * torch.randn(D, generator=g), 0.3 * torch.randn(D, generator=g)
     want = F.layer_norm(x, (D,), gamma, beta, 1e-6)
     y = torch.empty(rows, D, dtype=torch.bfloat16, device="cuda")
-    L.check(lib.hmm_op_layernorm_bf16(x.cuda().data_ptr(), gamma.cuda().data_ptr(), beta.cuda().data_ptr(),
+    xd, gd, bd = x.cuda(), gamma.cuda(), beta.cuda()
+    L.check(lib.hmm_op_layernorm_bf16(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(),
                                       y.data_ptr(), rows, D, 1e-6, L.stream_ptr()), "layernorm")
     _close_bf16(y, want, extra_atol=1e-5)
 
@@ -136,9 +138,11 @@ def test_attention(B, T, H, dh, bias, scale):
     bv = torch.randn(D, generator=g) * scale if bias else None
     want = _attention_ref(qkv, B, T, H, dh, bk, bv)
     out = torch.full((B * T, D), float("nan"), dtype=torch.bfloat16, device="cuda")
-    L.check(lib.hmm_op_attention_bf16(qkv.cuda().data_ptr(), out.data_ptr(), B, T, H, dh,
-                                      bk.cuda().data_ptr() if bias else None,
-                                      bv.cuda().data_ptr() if bias else None, L.stream_ptr()), "attention")
+    qd = qkv.cuda()
+    bkd, bvd = (bk.cuda(), bv.cuda()) if bias else (None, None)
+    L.check(lib.hmm_op_attention_bf16(qd.data_ptr(), out.data_ptr(), B, T, H, dh,
+                                      bkd.data_ptr() if bias else None,
+                                      bvd.data_ptr() if bias else None, L.stream_ptr()), "attention")
     got = out.float().cpu()
     assert torch.isfinite(got).all()
     # P is rounded to bf16 before P.V (as in every flash kernel): error <= 2^-9 * sum|p v| per element
@@ -170,7 +174,8 @@ def test_attention_one_hot_rows_pick_the_right_value():
         bk = k[T].reshape(D).cuda() if bias else None
         bv = v[T].reshape(D).cuda() if bias else None
         out = torch.empty(T, D, dtype=torch.bfloat16, device="cuda")
-        L.check(lib.hmm_op_attention_bf16(qkv.reshape(T, 3 * D).to(torch.bfloat16).cuda().data_ptr(), out.data_ptr(),
+        qd = qkv.reshape(T, 3 * D).to(torch.bfloat16).cuda()
+        L.check(lib.hmm_op_attention_bf16(qd.data_ptr(), out.data_ptr(),
                                           1, T, H, dh, bk.data_ptr() if bias else None,
                                           bv.data_ptr() if bias else None, L.stream_ptr()), "attention")
         want = v[torch.tensor([top[int(a)] for a in axis])].reshape(T, D)
