@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void scan_sims_kernel(const float4* __restrict
     }
 }
 
+
 // Descending bitonic sort of N keys in LDS by NT threads.
 template <int N, int NT>
 __device__ __forceinline__ void bitonic_sort_desc(uint64_t* s) {
@@ -98,13 +99,37 @@ __device__ __forceinline__ void bitonic_sort_desc(uint64_t* s) {
     }
 }
 
+// Descending bitonic sort of the first n2 (power of two) keys in LDS by the whole block.
+__device__ __forceinline__ void bitonic_sort_desc_rt(uint64_t* s, int n2) {
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
+                const int i = 2 * t - (t & (j - 1));
+                const int l = i + j;
+                const bool desc = (i & k) == 0;
+                const uint64_t a = s[i], b = s[l];
+                if ((a < b) == desc) { s[i] = b; s[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ int pow2_at_least(int n, int lo) {
+    int p = lo;
+    while (p < n) p <<= 1;
+    return p;
+}
+
 // Each block sorts one chunk and writes its best `k` keys (0-padded) to out[blockIdx.x*k ..].
 template <bool FROM_SIMS>
-__global__ __launch_bounds__(256) void topk_chunk_kernel(const void* __restrict__ in, int64_t n_in,
-                                                         int k, uint64_t* __restrict__ out) {
+__global__ __launch_bounds__(1024) void topk_chunk_kernel(const void* __restrict__ in, int64_t n_in,
+                                                          int k, uint64_t* __restrict__ out) {
     __shared__ uint64_t s[kChunk];
     const int64_t base = (int64_t)blockIdx.x * kChunk;
-    for (int t = threadIdx.x; t < kChunk; t += 256) {
+    const int64_t left = n_in - base;
+    const int n2 = pow2_at_least((int)(left < kChunk ? left : kChunk), 64);
+    for (int t = threadIdx.x; t < n2; t += 1024) {
         const int64_t g = base + t;
         uint64_t key = 0;
         if (g < n_in) {
@@ -118,8 +143,79 @@ __global__ __launch_bounds__(256) void topk_chunk_kernel(const void* __restrict_
         s[t] = key;
     }
     __syncthreads();
-    bitonic_sort_desc<kChunk, 256>(s);
-    for (int t = threadIdx.x; t < k; t += 256) out[(int64_t)blockIdx.x * k + t] = s[t];
+    bitonic_sort_desc_rt(s, n2);
+    for (int t = threadIdx.x; t < k; t += 1024) out[(int64_t)blockIdx.x * k + t] = t < n2 ? s[t] : 0ull;
+}
+
+// Fused path for k <= kFusedK: the streaming kernel keeps its own candidates.  Every wave appends the
+// order keys of its rows to a block-local LDS list; whenever the list could overflow, and once at the
+// end, the block sorts it and keeps its best k, which go to out[blockIdx.x*k ..] (0-padded).  Nothing
+// but k keys per block (8*k B) is written, and the follow-up passes see blocks*k keys instead of N.
+constexpr int kFusedK = 128;
+constexpr int kFusedCap = 1024;
+
+template <bool NT>
+__global__ __launch_bounds__(256) void scan_topk_kernel(const float4* __restrict__ store, int64_t n_rows,
+                                                        const float4* __restrict__ query, int k,
+                                                        uint64_t* __restrict__ out) {
+    __shared__ uint64_t cand[kFusedCap];
+    __shared__ int count;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    if (threadIdx.x == 0) count = 0;
+
+    float4 q[4];
+    float qs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        q[j] = query[j * 64 + lane];
+        qs = fmaf(q[j].x, q[j].x, qs); qs = fmaf(q[j].y, q[j].y, qs);
+        qs = fmaf(q[j].z, q[j].z, qs); qs = fmaf(q[j].w, q[j].w, qs);
+    }
+    const float q_len = sqrtf(wave_sum(qs));
+    __syncthreads();
+
+    const int64_t iters = (n_rows + n_waves * 2 - 1) / (n_waves * 2);     // same trip count for every wave
+    const int compact_every = (kFusedCap - k) / 8;                        // 8 rows per block per iteration
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t r = wave * 2 + it * n_waves * 2;
+        const bool one = r < n_rows, two = (r + 1) < n_rows;              // wave-uniform
+        if (one) {
+            const float4* p0 = store + r * 256 + lane;
+            const float4* p1 = p0 + (two ? 256 : 0);
+            float4 a[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = ld16<NT>(p0 + j * 64);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = ld16<NT>(p1 + j * 64);
+            float d0 = 0.f, s0 = 0.f, d1 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fma4(d0, s0, a[j], q[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fma4(d1, s1, b[j], q[j]);
+            d0 = wave_sum(d0); s0 = wave_sum(s0);
+            d1 = wave_sum(d1); s1 = wave_sum(s1);
+            if (lane == 0) {
+                const int pos = atomicAdd(&count, two ? 2 : 1);
+                cand[pos] = ((uint64_t)order_bits(d0 / (sqrtf(s0) * q_len)) << 32) | (uint64_t)(uint32_t)r;
+                if (two)
+                    cand[pos + 1] = ((uint64_t)order_bits(d1 / (sqrtf(s1) * q_len)) << 32) | (uint64_t)(uint32_t)(r + 1);
+            }
+        }
+        if ((it + 1) % compact_every == 0 || it + 1 == iters) {          // block-uniform
+            __syncthreads();
+            const int n = count;
+            const int n2 = pow2_at_least(n, 64);
+            for (int t = n + threadIdx.x; t < n2; t += 256) cand[t] = 0ull;
+            __syncthreads();
+            bitonic_sort_desc_rt(cand, n2);
+            if (threadIdx.x == 0) count = n < k ? n : k;
+            __syncthreads();
+        }
+    }
+    const int n = count;
+    for (int t = threadIdx.x; t < k; t += 256) out[(int64_t)blockIdx.x * k + t] = t < n ? cand[t] : 0ull;
 }
 
 __global__ void keys_from_sims_kernel(const float* __restrict__ sims, int64_t n, int64_t n_pad,
@@ -209,6 +305,7 @@ static ScanPlan make_plan(int64_t n, int k) {
         a = (size_t)p.n_pad * 8; b = 0;
     } else {
         int64_t blocks1 = (n + kChunk - 1) / kChunk;
+        if (p.k_eff <= kFusedK && blocks1 < kScanBlocks) blocks1 = kScanBlocks;   // fused path: k keys per scan block
         int64_t kk = p.k_eff > 0 ? p.k_eff : 1;
         a = (size_t)blocks1 * kk * 8;
         int64_t blocks2 = (blocks1 * kk + kChunk - 1) / kChunk;
@@ -240,11 +337,32 @@ static int run_scan(const float* store, int64_t n, int dim, const float* query, 
     int64_t waves_needed = (n + 1) / 2;
     int blocks = (int)((waves_needed + 3) / 4);
     if (blocks > kScanBlocks) blocks = kScanBlocks;
+    *k_eff = p.k_eff;
+
+    if (!p.full_sort && n > kChunk && p.k_eff <= kFusedK) {
+        // fused: the streaming kernel emits k candidates per block; reduce blocks*k keys by chunk sorts
+        scan_topk_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n,
+                                                       reinterpret_cast<const float4*>(query), p.k_eff, buf_a);
+        HMM_LAUNCH_CHECK();
+        int64_t count = (int64_t)blocks * p.k_eff;
+        uint64_t* cur = buf_a;
+        uint64_t* nxt = buf_b;
+        do {
+            const int64_t nblk = (count + kChunk - 1) / kChunk;
+            topk_chunk_kernel<false><<<(unsigned)nblk, 1024, 0, st>>>(cur, count, p.k_eff, nxt);
+            HMM_LAUNCH_CHECK();
+            count = nblk * p.k_eff;
+            uint64_t* t = cur; cur = nxt; nxt = t;
+            if (nblk == 1) break;
+        } while (true);
+        *best = cur;
+        return HMM_OK;
+    }
+
     scan_sims_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n,
                                                    reinterpret_cast<const float4*>(query), sims);
     HMM_LAUNCH_CHECK();
 
-    *k_eff = p.k_eff;
     if (p.full_sort) {
         const int64_t np = p.n_pad;
         keys_from_sims_kernel<<<(unsigned)((np + 255) / 256), 256, 0, st>>>(sims, n, np, buf_a);
@@ -259,14 +377,14 @@ static int run_scan(const float* store, int64_t n, int dim, const float* query, 
     }
     int64_t count = n;
     int64_t nblk = (count + kChunk - 1) / kChunk;
-    topk_chunk_kernel<true><<<(unsigned)nblk, 256, 0, st>>>(sims, count, p.k_eff, buf_a);
+    topk_chunk_kernel<true><<<(unsigned)nblk, 1024, 0, st>>>(sims, count, p.k_eff, buf_a);
     HMM_LAUNCH_CHECK();
     uint64_t* cur = buf_a;
     uint64_t* nxt = buf_b;
     while (nblk > 1) {
         count = nblk * p.k_eff;
         nblk = (count + kChunk - 1) / kChunk;
-        topk_chunk_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(cur, count, p.k_eff, nxt);
+        topk_chunk_kernel<false><<<(unsigned)nblk, 1024, 0, st>>>(cur, count, p.k_eff, nxt);
         HMM_LAUNCH_CHECK();
         uint64_t* t = cur; cur = nxt; nxt = t;
     }

@@ -25,6 +25,68 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+
+// Shared epilogue.  A lane holds C[m][n..n+3] for m = m_lane + 16*mi, n = n_lane + 16*ni.  The bias
+// vectors are loaded once per lane (not per store), and the fp32 residual read-modify-write is
+// software-pipelined one row-block ahead so that its load latency is not paid per element.
+template <int EPI, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float* __restrict__ bias,
+                                              void* __restrict__ Cout, int M, int N, int m_lane, int n_lane) {
+    float4 bv[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+        bv[ni] = bias ? *reinterpret_cast<const float4*>(bias + n_lane + ni * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
+        float* C = static_cast<float*>(Cout);
+        float4 xin[2][NI];
+        auto load_row = [&](int mi, float4 (&dst)[NI]) {
+            const int m = m_lane + mi * 16;
+            if (m < M) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    dst[ni] = *reinterpret_cast<const float4*>(C + (size_t)m * N + n_lane + ni * 16);
+            }
+        };
+        load_row(0, xin[0]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if (mi + 1 < MI) load_row(mi + 1, xin[(mi + 1) & 1]);
+            const int m = m_lane + mi * 16;
+            if (m < M) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const float4 x = xin[mi & 1][ni];
+                    const f32x4 v = acc[mi][ni];
+                    *reinterpret_cast<float4*>(C + (size_t)m * N + n_lane + ni * 16) =
+                        make_float4(x.x + v[0] + bv[ni].x, x.y + v[1] + bv[ni].y, x.z + v[2] + bv[ni].z, x.w + v[3] + bv[ni].w);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m_lane + mi * 16;
+            if (m >= M) continue;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                f32x4 v = acc[mi][ni];
+                v[0] += bv[ni].x; v[1] += bv[ni].y; v[2] += bv[ni].z; v[3] += bv[ni].w;
+                const size_t o = (size_t)m * N + n_lane + ni * 16;
+                if constexpr (EPI == HMM_EPI_F32) {
+                    *reinterpret_cast<float4*>(static_cast<float*>(Cout) + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    if constexpr (EPI == HMM_EPI_BIAS_GELU_BF16) {
+                        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+                    }
+                    bf16x4 o4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(Cout) + o) = o4;
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
@@ -120,36 +182,207 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
         __syncthreads();
     }
 
-    // epilogue: lane holds C[m][n .. n+3], m = m0 + wm*TM + mi*16 + (lane&15), n = n0 + wn*TN + ni*16 + 4*(lane>>4)
+    // epilogue: lane holds C[m][n .. n+3]
+    gemm_epilogue<EPI, MI, NI>(acc, bias, Cout, M, N, m0 + wm * TM + (lane & 15), n0 + wn * TN + 4 * (lane >> 4));
+}
+
+
+
+// ------------------------------------------------------------------------------------------------
+// Ping-pong variant: 256x256x64 tile, 8 waves as 2 (M) x 4 (N), wave tile 128x64 = 4 quadrants of
+// 64x32; one quadrant (16 MFMAs, full K=64) per phase, 4 phases per K-tile.
+//
+// A K-tile lives in LDS as four 16-KiB half-tiles chosen so that each one dies early:
+//   A_lo = the first 64 rows of every wave-row, A_hi = the second 64; B_lo / B_hi likewise in N.
+//   phase 1 (quadrant lo,lo) reads A_lo + B_lo into registers     -> A_lo, B_lo are dead after P1
+//   phase 2 (lo,hi)          reads B_hi, reuses the A_lo registers -> B_hi dead after P2
+//   phase 3 (hi,hi)          reads A_hi, reuses the B_hi registers -> A_hi dead after P3
+//   phase 4 (hi,lo)          reads nothing (B_lo registers kept)
+// so every phase can re-stage exactly one dead half-tile (2 x global_load_lds_dwordx4 per wave):
+//   P1: (t+1).A_hi   P2: (t+2).A_lo   P3: (t+2).B_lo   P4: (t+2).B_hi
+// i.e. the LDS-DMA stream runs ~1.75 K-tiles ahead of the MFMAs and is never drained in the loop:
+// the only wait is a counted vmcnt(6) in P4, which retires K-tile t+1 while the three youngest
+// half-tiles (of t+2) stay in flight.  Waves 4-7 run one barrier behind waves 0-3, so on every
+// SIMD one wave issues its 16-MFMA burst while its partner does its LDS reads and DMA issue.
+// Hazards: a half-tile is re-staged only in a phase after the one whose reads were retired by
+// lgkmcnt(0) *before* that phase's first barrier (WAR); staged data is read only in a phase after
+// the barrier that follows every wave's counted vmcnt (RAW).
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int F = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+    void* __restrict__ Cout, int M, int N, int K, int tiles_n) {
+    // F: experiment flags (0 in production).  1: P1 waits only for its kh=0 fragments before the
+    // barrier; 2: no s_setprio; 4: no stagger between the wave groups; 8: ablation, no in-loop DMA;
+    // 16: ablation, no in-loop LDS reads (8 and 16 give wrong results; timing only).
+    constexpr bool F_PARTIAL = F & 1, F_NOPRIO = F & 2, F_NOSTAG = F & 4, F_NODMA = F & 8, F_NOLDS = F & 16;
+    constexpr int HALF = 16384, TILE = 4 * HALF;
+    constexpr int H_ALO = 0, H_AHI = HALF, H_BLO = 2 * HALF, H_BHI = 3 * HALF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = (swz / tiles_n) * 256, n0 = (swz % tiles_n) * 256;
+
+    // staging sources: half-tile local row lr = (wave + 8j)*8 + (lane>>3), 16-B chunk (lane&7) un-swizzled
+    const bf16_t* src_alo[2]; const bf16_t* src_ahi[2]; const bf16_t* src_blo[2]; const bf16_t* src_bhi[2];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * TM + mi * 16 + (lane & 15);
-        if (m >= M) continue;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + wn * TN + ni * 16 + 4 * (lane >> 4);
-            f32x4 v = acc[mi][ni];
-            if (bias != nullptr) {
-                const float4 b = *reinterpret_cast<const float4*>(bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            const size_t o = (size_t)m * N + n;
-            if constexpr (EPI == HMM_EPI_BIAS_BF16 || EPI == HMM_EPI_BIAS_GELU_BF16) {
-                if constexpr (EPI == HMM_EPI_BIAS_GELU_BF16) {
-                    v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-                }
-                bf16x4 o4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(Cout) + o) = o4;
-            } else if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
-                float4* p = reinterpret_cast<float4*>(static_cast<float*>(Cout) + o);
-                float4 x = *p;
-                x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
-                *p = x;
-            } else {
-                *reinterpret_cast<float4*>(static_cast<float*>(Cout) + o) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
+    for (int j = 0; j < 2; ++j) {
+        const int lr = (wave + 8 * j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((lr >> 1) & 7);
+        const int arow = (lr & 63) + (lr >> 6) * 128;           // rows 0..63 of wave-row 0 / wave-row 1
+        int g0 = m0 + arow, g1 = m0 + arow + 64;
+        g0 = g0 < M ? g0 : M - 1;
+        g1 = g1 < M ? g1 : M - 1;
+        src_alo[j] = A + (size_t)g0 * K + c * 8;
+        src_ahi[j] = A + (size_t)g1 * K + c * 8;
+        const int bcol = (lr >> 5) * 64 + (lr & 31);             // cols 0..31 of each wave-column
+        src_blo[j] = W + (size_t)(n0 + bcol) * K + c * 8;
+        src_bhi[j] = W + (size_t)(n0 + bcol + 32) * K + c * 8;
     }
+#define HMM_STAGE(src, kt, buf, half)                                                                       \
+    do {                                                                                                    \
+        __builtin_amdgcn_global_load_lds(HMM_GLB_PTR(src[0] + (kt) * 64),                                   \
+                                         HMM_LDS_PTR(smem + (buf) * TILE + (half) + wave * 1024), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds(HMM_GLB_PTR(src[1] + (kt) * 64),                                   \
+                                         HMM_LDS_PTR(smem + (buf) * TILE + (half) + (wave + 8) * 1024), 16, 0, 0); \
+    } while (0)
+
+    // fragment read bases (bytes inside a half-tile)
+    const int fsw = (lane & 15) >> 1;
+    const int ck0 = ((lane >> 4) ^ fsw) * 16, ck1 = ((4 + (lane >> 4)) ^ fsw) * 16;
+    const char* a_rd = smem + (wm * 64 + (lane & 15)) * 128;
+    const char* b_rd = smem + (wn * 32 + (lane & 15)) * 128;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], blo[2][2], bhi[2][2];
+
+#define HMM_READ_A_KH(buf, half, kh, ck)                                                              \
+    if (!F_NOLDS || t_first) {                                                                        \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
+        af[mi][kh] = *reinterpret_cast<const bf16x8*>(a_rd + (buf) * TILE + (half) + mi * 2048 + ck); }
+#define HMM_READ_B_KH(dst, buf, half, kh, ck)                                                         \
+    if (!F_NOLDS || t_first) {                                                                        \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
+        dst[ni][kh] = *reinterpret_cast<const bf16x8*>(b_rd + (buf) * TILE + (half) + ni * 2048 + ck); }
+#define HMM_READ_A(buf, half) HMM_READ_A_KH(buf, half, 0, ck0) HMM_READ_A_KH(buf, half, 1, ck1)
+#define HMM_READ_B(dst, buf, half) HMM_READ_B_KH(dst, buf, half, 0, ck0) HMM_READ_B_KH(dst, buf, half, 1, ck1)
+#define HMM_MFMA_HALF(mo, no, bsrc, kh)                                                               \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
+        acc[(mo) + mi][(no) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[ni][kh], af[mi][kh], \
+                                                                            acc[(mo) + mi][(no) + ni], 0, 0, 0);
+#define HMM_MFMA_QUAD(mo, no, bsrc)                                                                   \
+    if constexpr (!F_NOPRIO) __builtin_amdgcn_s_setprio(1);                                           \
+    HMM_MFMA_HALF(mo, no, bsrc, 0) HMM_MFMA_HALF(mo, no, bsrc, 1)                                      \
+    if constexpr (!F_NOPRIO) __builtin_amdgcn_s_setprio(0);
+#define HMM_MFMA_QUAD_SPLIT(mo, no, bsrc)                                                             \
+    if constexpr (!F_NOPRIO) __builtin_amdgcn_s_setprio(1);                                           \
+    HMM_MFMA_HALF(mo, no, bsrc, 0)                                                                    \
+    __builtin_amdgcn_sched_barrier(0); HMM_LGKM0(); __builtin_amdgcn_sched_barrier(0);                \
+    HMM_MFMA_HALF(mo, no, bsrc, 1)                                                                    \
+    if constexpr (!F_NOPRIO) __builtin_amdgcn_s_setprio(0);
+#define HMM_BAR()                              \
+    __builtin_amdgcn_sched_barrier(0);         \
+    __builtin_amdgcn_s_barrier();              \
+    __builtin_amdgcn_sched_barrier(0);
+#define HMM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+    const int KT = K >> 6;                                    // even, >= 2 (checked by the launcher)
+    // prologue: K-tile 0 complete, K-tile 1 minus A_hi (which P1 of tile 0 stages)
+    HMM_STAGE(src_alo, 0, 0, H_ALO); HMM_STAGE(src_blo, 0, 0, H_BLO);
+    HMM_STAGE(src_bhi, 0, 0, H_BHI); HMM_STAGE(src_ahi, 0, 0, H_AHI);
+    HMM_STAGE(src_alo, 1, 1, H_ALO); HMM_STAGE(src_blo, 1, 1, H_BLO); HMM_STAGE(src_bhi, 1, 1, H_BHI);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    HMM_BAR();
+    if (!F_NOSTAG && wm == 1) { HMM_BAR(); }                  // waves 4-7 run one barrier behind
+
+#define HMM_KTILE(t, buf)                                                                 \
+    {                                                                                     \
+        /* P1: quadrant (lo,lo) */                                                        \
+        const bool t_first = (t) < 2;                                                     \
+        if constexpr (F_PARTIAL) {                                                        \
+            HMM_READ_A_KH(buf, H_ALO, 0, ck0) HMM_READ_B_KH(blo, buf, H_BLO, 0, ck0)      \
+            HMM_READ_A_KH(buf, H_ALO, 1, ck1) HMM_READ_B_KH(blo, buf, H_BLO, 1, ck1)      \
+            if (!F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");                            \
+            HMM_BAR() HMM_MFMA_QUAD_SPLIT(0, 0, blo) HMM_BAR()                            \
+        } else {                                                                          \
+            HMM_READ_A(buf, H_ALO) HMM_READ_B(blo, buf, H_BLO)                            \
+            if (!F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
+            HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(0, 0, blo) HMM_BAR()                     \
+        }                                                                                 \
+        /* P2: (lo,hi) */                                                                 \
+        HMM_READ_B(bhi, buf, H_BHI)                                                       \
+        if (!F_NODMA && (t) + 2 < KT) HMM_STAGE(src_alo, (t) + 2, buf, H_ALO);            \
+        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(0, 2, bhi) HMM_BAR()                         \
+        /* P3: (hi,hi) */                                                                 \
+        HMM_READ_A(buf, H_AHI)                                                            \
+        if (!F_NODMA && (t) + 2 < KT) HMM_STAGE(src_blo, (t) + 2, buf, H_BLO);            \
+        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(4, 2, bhi) HMM_BAR()                         \
+        /* P4: (hi,lo) */                                                                 \
+        if (!F_NODMA && (t) + 2 < KT) {                                                   \
+            HMM_STAGE(src_bhi, (t) + 2, buf, H_BHI);                                      \
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                              \
+        } else {                                                                          \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              \
+        }                                                                                 \
+        HMM_BAR() HMM_MFMA_QUAD(4, 0, blo) HMM_BAR()                                      \
+    }
+
+    for (int t = 0; t < KT; t += 2) {
+        HMM_KTILE(t, 0)
+        HMM_KTILE(t + 1, 1)
+    }
+    if (!F_NOSTAG && wm == 0) { HMM_BAR(); }                  // re-align the two wave groups
+#undef HMM_KTILE
+#undef HMM_STAGE
+#undef HMM_READ_A
+#undef HMM_READ_B
+#undef HMM_MFMA_QUAD
+#undef HMM_MFMA_QUAD_SPLIT
+#undef HMM_MFMA_HALF
+#undef HMM_READ_A_KH
+#undef HMM_READ_B_KH
+
+    gemm_epilogue<EPI, 8, 4>(acc, bias, Cout, M, N, m0 + wm * 128 + (lane & 15), n0 + wn * 64 + 4 * (lane >> 4));
+}
+
+template <int EPI, int F = 0>
+static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, hipStream_t st) {
+    constexpr int LDS = 2 * 4 * 16384;
+    auto kern = gemm_bf16_pp_kernel<EPI, F>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
+    kern<<<tiles_m * tiles_n, 512, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+
+static int launch_gemm_pp_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                              int epi, hipStream_t st) {
+    switch (epi) {
+        case HMM_EPI_BIAS_BF16:      return launch_gemm_pp<HMM_EPI_BIAS_BF16>(A, W, bias, C, M, N, K, st);
+        case HMM_EPI_BIAS_GELU_BF16: return launch_gemm_pp<HMM_EPI_BIAS_GELU_BF16>(A, W, bias, C, M, N, K, st);
+        case HMM_EPI_BIAS_RESID_F32: return launch_gemm_pp<HMM_EPI_BIAS_RESID_F32>(A, W, bias, C, M, N, K, st);
+        case HMM_EPI_F32:            return launch_gemm_pp<HMM_EPI_F32>(A, W, bias, C, M, N, K, st);
+    }
+    set_error("gemm: unknown epilogue %d", epi);
+    return HMM_E_INVALID;
 }
 
 template <int BM, int BN, int WM, int WN, int EPI>
@@ -181,7 +414,7 @@ static int launch_gemm_epi(const bf16_t* A, const bf16_t* W, const float* bias, 
     return HMM_E_INVALID;
 }
 
-int g_gemm_default_variant = 0;
+int g_gemm_default_variant = 4;      // ping-pong 256x256 kernel + peeled tail (see gemm_bf16)
 
 int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int epi,
               int variant, hipStream_t st) {
@@ -190,8 +423,40 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
                 "gemm: unsupported shape M=%d N=%d K=%d (need K%%64==0, N%%128==0)", M, N, K);
     HMM_REQUIRE(epi == HMM_EPI_F32 || bias != nullptr, HMM_E_INVALID, "gemm: epilogue %d needs a bias", epi);
     if (variant < 0) variant = g_gemm_default_variant;
+    if (variant == 3 && (N % 256 != 0 || K % 128 != 0)) variant = 2;
     if (variant == 2 && N % 256 != 0) variant = 1;
+    if (variant >= 100 && epi == HMM_EPI_BIAS_BF16 && N % 256 == 0 && K % 128 == 0) {   // experiment builds
+        switch (variant - 100) {
+            case 1:  return launch_gemm_pp<HMM_EPI_BIAS_BF16, 1>(A, W, bias, C, M, N, K, st);
+            case 2:  return launch_gemm_pp<HMM_EPI_BIAS_BF16, 2>(A, W, bias, C, M, N, K, st);
+            case 4:  return launch_gemm_pp<HMM_EPI_BIAS_BF16, 4>(A, W, bias, C, M, N, K, st);
+            case 8:  return launch_gemm_pp<HMM_EPI_BIAS_BF16, 8>(A, W, bias, C, M, N, K, st);
+            case 16: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 16>(A, W, bias, C, M, N, K, st);
+            case 24: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 24>(A, W, bias, C, M, N, K, st);
+        }
+    }
+    if (variant == 4) {
+        // Tile quantisation: with 256 CUs and one 256x256 tile per CU, T tiles take ceil(T/256) rounds.
+        // ViT-H at batch 256 has 257 M-tiles (257 = 256 patches + cls per image), i.e. 5..20 tiles left
+        // over for a whole extra round.  Peel the last M-tile(s) off into a small-tile launch when that
+        // makes the main launch an exact number of rounds.
+        if (N % 256 != 0 || K % 128 != 0) return gemm_bf16(A, W, bias, C, M, N, K, epi, 2, st);
+        const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
+        const long tiles = (long)tiles_m * tiles_n;
+        int peel = 0;
+        if (tiles > 256 && tiles % 256 != 0 && tiles % 256 <= 64)
+            for (int p = 1; p <= 2 && !peel; ++p)
+                if (((long)(tiles_m - p) * tiles_n) % 256 == 0) peel = p;
+        if (!peel) return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, st);
+        const int m_main = (tiles_m - peel) * 256;
+        int rc = launch_gemm_pp_epi(A, W, bias, C, m_main, N, K, epi, st);
+        if (rc != HMM_OK) return rc;
+        const size_t esz = (epi == HMM_EPI_BIAS_BF16 || epi == HMM_EPI_BIAS_GELU_BF16) ? 2 : 4;
+        return launch_gemm_epi<128, 128, 2, 2>(A + (size_t)m_main * K, W, bias,
+                                               static_cast<char*>(C) + (size_t)m_main * N * esz, M - m_main, N, K, epi, st);
+    }
     switch (variant) {
+        case 3: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, st);
         case 0: return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
         case 1: return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
         case 2: return launch_gemm_epi<256, 256, 2, 4>(A, W, bias, C, M, N, K, epi, st);

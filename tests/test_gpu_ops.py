@@ -36,7 +36,7 @@ def _close_bf16(got, want, extra_atol=0.0):
     assert not bad.any(), f"{int(bad.sum())} / {bad.numel()} off; worst {float((got - want).abs().max()):.4g}"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(257, 1280, 1280), (514, 3840, 1280), (300, 5120, 1280), (257, 1280, 5120),
                                    (1, 1024, 1280), (130, 768, 256), (512, 1280, 640), (1000, 2304, 768)])
 def test_gemm_bias_bf16(variant, M, N, K):
@@ -54,7 +54,7 @@ def test_gemm_bias_bf16(variant, M, N, K):
     assert torch.isnan(c[M:].float()).all(), "rows past M were written"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_gemm_gelu_resid_f32_epilogues(variant):
     L, lib = _lib()
     M, N, K = 771, 1280, 1280
@@ -82,6 +82,28 @@ def test_gemm_gelu_resid_f32_epilogues(variant):
     torch.testing.assert_close(y.cpu(), lin - bias, rtol=2e-5, atol=2e-4)
 
 
+def test_gemm_cfg2_rows_peeled_tail():
+    """M = 65792 (256 frames x 257 tokens): the default path peels the 257th M-tile into a second
+    launch; check both launches against torch on sampled rows, including the seam and the last row."""
+    L, lib = _lib()
+    M, N, K = 65792, 1280, 1280
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = (torch.randn(M, K, device="cuda", generator=g)).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    c = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K,
+                                 EPI_BIAS_BF16, L.stream_ptr()), "gemm")
+    rows = torch.cat([torch.arange(0, 300), torch.arange(65280, 65792), torch.randint(0, M, (500,))]).cuda()
+    want = a[rows].float() @ w.float().T + bias
+    _close_bf16(c[rows], want)
+    x0 = torch.randn(M, N, device="cuda", generator=g)
+    x = x0.clone()
+    L.check(lib.hmm_op_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), x.data_ptr(), M, N, K,
+                                 EPI_BIAS_RESID_F32, L.stream_ptr()), "gemm")
+    torch.testing.assert_close(x[rows], x0[rows] + want, rtol=2e-5, atol=3e-4)
+
+
 def test_gemm_identity_asymmetric():
     """A = I against an asymmetric W catches a transposed / permuted accumulator mapping exactly."""
     L, lib = _lib()
@@ -90,7 +112,7 @@ def test_gemm_identity_asymmetric():
     w = (torch.arange(N * K).reshape(N, K) % 251 - 125).float().to(torch.bfloat16)   # exact in bf16
     y = torch.empty(K, N, dtype=torch.float32, device="cuda")
     ad, wd = a.cuda(), w.cuda()
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3, 4):
         y.zero_()
         L.check(lib.hmm_dev_gemm_bf16_variant(ad.data_ptr(), wd.data_ptr(), None, y.data_ptr(), K, N, K,
                                               EPI_F32, variant, L.stream_ptr()), "gemm")

@@ -42,12 +42,13 @@ def test_matches_oracle(n, clusters, sigma, thr):
 
 
 def test_method_dropin_and_device_input():
-    from hippomm_amd.consolidation import _select_key_frames, select_key_frames_device
+    from hippomm_amd import consolidation
+    from hippomm_amd.consolidation import select_key_frames_device
     f, t = recipes.select_case("n32_clusters6")
     want = GOLD["n32_clusters6"]["kept"]
 
     class Host:                       # stands for HippocampalMemory: the method ignores self
-        _select_key_frames = _select_key_frames
+        _select_key_frames = consolidation._select_key_frames
     assert Host()._select_key_frames(f, t).tolist() == want
     assert select_key_frames_device(torch.from_numpy(f).cuda()).cpu().tolist() == want
 
