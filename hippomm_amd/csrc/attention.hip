@@ -60,6 +60,8 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
     const bf16_t* base = qkv + (size_t)b * T * row_stride + h * DH;
 
     const int r = lane & 31, hh = lane >> 5;
+    const int hh4 = 4 * hh;
+    const float neg_inf = -INFINITY;
     const int nqt = (T + 31) >> 5;
 
     // this wave's first query fragments: issued before the K/V staging so that they ride along
@@ -74,28 +76,32 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
 
     // ---- stage K and V (row-major) into LDS: all global loads first, then the LDS writes ------
     {
-        bf16x8 kv[PER_THREAD], vv[PER_THREAD];
+        uint4 kv[PER_THREAD], vv[PER_THREAD];            // raw 16-B chunks (8 bf16): no per-element handling
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
             const int idx = tid + i * NT;
             const int row = idx / CPR, c = idx - row * CPR;
-            kv[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            vv[i] = kv[i];
-            if (row < T) {                               // rows >= T (incl. idx >= NCHUNK) stay zero
-                const bf16_t* p = base + (size_t)row * row_stride + c * 8;
-                kv[i] = *reinterpret_cast<const bf16x8*>(p + D);
-                vv[i] = *reinterpret_cast<const bf16x8*>(p + 2 * D);
-            }
+            const int rr = row < T ? row : T - 1;        // clamp: always a valid address; rows >= T are not written
+            const bf16_t* p = base + (size_t)rr * row_stride + c * 8;
+            kv[i] = *reinterpret_cast<const uint4*>(p + D);
+            vv[i] = *reinterpret_cast<const uint4*>(p + 2 * D);
+        }
+        // rows T .. NKEY-1: zeros (the bias row, if any, is filled after the barrier)
+        for (int idx = T * CPR + tid; idx < NCHUNK; idx += NT) {
+            const int row = idx / CPR, c = idx - row * CPR;
+            *reinterpret_cast<uint4*>(k_lds + row * C::KROW + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(v_lds + row * C::VROW + c * 16) = make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
             const int idx = tid + i * NT;
             const int row = idx / CPR, c = idx - row * CPR;
-            if (idx < NCHUNK && !(bias_k != nullptr && row == T)) {
-                *reinterpret_cast<bf16x8*>(k_lds + row * C::KROW + c * 16) = kv[i];
-                *reinterpret_cast<bf16x8*>(v_lds + row * C::VROW + c * 16) = vv[i];
+            if (row < T) {
+                *reinterpret_cast<uint4*>(k_lds + row * C::KROW + c * 16) = kv[i];
+                *reinterpret_cast<uint4*>(v_lds + row * C::VROW + c * 16) = vv[i];
             }
         }
+        __syncthreads();
         if (bias_k != nullptr && tid < DH) {             // the add_bias_kv position: row T
             *reinterpret_cast<bf16_t*>(k_lds + T * C::KROW + tid * 2) = (bf16_t)bias_k[h * DH + tid];
             *reinterpret_cast<bf16_t*>(v_lds + T * C::VROW + tid * 2) = (bf16_t)bias_v[h * DH + tid];
@@ -144,21 +150,31 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
                     __builtin_amdgcn_sched_barrier(0);     // one tile's K fragments live at a time
                 }
             }
-            // mask keys >= Lk (only tiles that can contain them), chunk max
+            // mask keys >= Lk.  Only the tile(s) straddling Lk need it (wave-uniform branch); the compare
+            // and select are opaque asm so that the compiler neither hoists 144 lane masks into SGPRs
+            // nor if-converts the branch.
             float mc = -INFINITY;
 #pragma unroll
             for (int i = 0; i < CHT; ++i) {
                 const int kt = ch * CHT + i;
                 if (kt < NKT) {
-                    const bool may_mask = (kt + 1) * 32 > Lk;        // wave-uniform
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        if (may_mask) {
-                            const int key = kt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                            if (key >= Lk) s[i][reg] = -INFINITY;
-                        }
-                        mc = fmaxf(mc, s[i][reg]);
+                    if ((kt + 1) * 32 > Lk) {
+                        const int rel = Lk - kt * 32 - hh4;          // key masked iff (reg&3)+8*(reg>>2) >= rel
+#define HMM_MASK1(REG, KC)                                                                         \
+    {                                                                                              \
+        float v = s[i][REG];                                                                       \
+        asm volatile("v_cmp_ge_i32 vcc, " #KC ", %1\n\tv_cndmask_b32 %0, %0, %2, vcc"              \
+                     : "+v"(v) : "v"(rel), "v"(neg_inf) : "vcc");                                  \
+        s[i][REG] = v;                                                                             \
+    }
+                        HMM_MASK1(0, 0) HMM_MASK1(1, 1) HMM_MASK1(2, 2) HMM_MASK1(3, 3)
+                        HMM_MASK1(4, 8) HMM_MASK1(5, 9) HMM_MASK1(6, 10) HMM_MASK1(7, 11)
+                        HMM_MASK1(8, 16) HMM_MASK1(9, 17) HMM_MASK1(10, 18) HMM_MASK1(11, 19)
+                        HMM_MASK1(12, 24) HMM_MASK1(13, 25) HMM_MASK1(14, 26) HMM_MASK1(15, 27)
+#undef HMM_MASK1
                     }
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) mc = fmaxf(mc, s[i][reg]);
                 }
             }
             mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
