@@ -98,19 +98,21 @@ def scan_bench(do_cpu):
     import ctypes as C
     from hippomm_amd import _lib as L
     lib = L.load()
-    lib.hmm_dev_scan_sims.restype = C.c_int
-    lib.hmm_dev_scan_sims.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
-    sims = torch.empty(SCAN_ROWS, dtype=torch.float32, device="cuda")
-    ms_kernel = event_time_ms(lambda: L.check(lib.hmm_dev_scan_sims(rows.data_ptr(), SCAN_ROWS, q.data_ptr(),
-                                                                    sims.data_ptr(), L.stream_ptr()), "scan"), 20)
+    lib.hmm_dev_scan_topk_only.restype = C.c_int
+    lib.hmm_dev_scan_topk_only.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    cand = torch.empty(2048 * SCAN_K, dtype=torch.int64, device="cuda")
+    ms_kernel = event_time_ms(lambda: L.check(lib.hmm_dev_scan_topk_only(rows.data_ptr(), SCAN_ROWS, q.data_ptr(), SCAN_K,
+                                                                         cand.data_ptr(), L.stream_ptr()), "scan"), 20)
     algo_bytes = SCAN_ROWS * 4096.0
     out = {
         "metric": "cosine-scan GB/s (feature_search, 1M x 1024 fp32 store, top-32, 1 query)",
         "value": round(algo_bytes / ms_query / 1e6, 1), "unit": "GB/s", "ms_per_query": round(ms_query, 4),
         "dtype": "f32",
-        "roofline": {"bound": "hbm", "kernel": "scan_sims_kernel", "achieved": round(algo_bytes / ms_kernel / 1e6, 1),
+        "roofline": {"bound": "hbm", "kernel": "scan_topk_kernel", "achieved": round(algo_bytes / ms_kernel / 1e6, 1),
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(algo_bytes / ms_kernel / 1e6 / PEAK_HBM_GBS, 4),
-                     "traffic": None, "bytes_per_launch": algo_bytes, "ms_per_launch": round(ms_kernel, 4)},
+                     # PMC pass (profiles/r1_scan_pmc_summary.json): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE
+                     "traffic": 4096643072, "traffic_source": "profiles/r1_scan_pmc_summary.json",
+                     "bytes_per_launch": algo_bytes, "ms_per_launch": round(ms_kernel, 4)},
     }
     if do_cpu:
         from oracle.vector_ops_oracle import top_k_cosine_similarity_oracle

@@ -454,3 +454,16 @@ extern "C" int hmm_dev_scan_sims(const float* store_dev, int64_t n_rows, const f
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
+
+// Timing hook: the fused streaming + block-top-k kernel alone (the dominant kernel of a query).
+extern "C" int hmm_dev_scan_topk_only(const float* store_dev, int64_t n_rows, const float* query_dev, int k,
+                                      uint64_t* cand_dev /* [2048*k] */, hmm_stream_t stream) {
+    HMM_REQUIRE(k >= 1 && k <= kFusedK, HMM_E_INVALID, "scan_topk_only: k out of range");
+    int64_t waves_needed = (n_rows + 1) / 2;
+    int blocks = (int)((waves_needed + 3) / 4);
+    if (blocks > kScanBlocks) blocks = kScanBlocks;
+    scan_topk_kernel<true><<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
+        reinterpret_cast<const float4*>(store_dev), n_rows, reinterpret_cast<const float4*>(query_dev), k, cand_dev);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
