@@ -31,18 +31,21 @@ struct AttnCfg {
     static constexpr int VROW = 192;                // V row stride, bytes (>= 2*32*DT)
     static constexpr int K_BYTES = NKEY * KROW;
     static constexpr int V_BYTES = NKEY * VROW;
-    static constexpr int LDS = K_BYTES + V_BYTES;
+    static constexpr int X_FLOATS = DH + 2;         // cooperative extra-query partial: O[DH], m, l
+    static constexpr int X_BYTES = (NKT * X_FLOATS * 4 + 15) / 16 * 16;
+    static constexpr int LDS = K_BYTES + V_BYTES + X_BYTES;
     static constexpr int CH = 3;                    // key tiles per online-softmax chunk
     static constexpr int NCH = (NKT + CH - 1) / CH;
     static_assert(DT * 64 <= VROW, "V row must cover every d tile a tr-read touches");
 };
 
 constexpr int kAttnWaves = 8;
+int g_attn_reverse = 1;   // tuning hook: walk images last-to-first (Infinity-Cache locality after the QKV GEMM)
 
 template <int DH, int NKT>
 __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T, int Lk, int H,
-    const float* __restrict__ bias_k, const float* __restrict__ bias_v, float scale_log2e) {
+    const float* __restrict__ bias_k, const float* __restrict__ bias_v, float scale_log2e, int reverse) {
     using C = AttnCfg<DH, NKT>;
     constexpr int NT = kAttnWaves * 64;
     constexpr int CPR = DH / 8;                      // 16-B chunks per K/V row
@@ -54,7 +57,11 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    // walk the images backwards: the producer (QKV GEMM) wrote the last images last, so they are the
+    // ones still resident in the 256-MiB Infinity Cache when this kernel starts
+    const int b_lin = blockIdx.x / H;
+    const int b = (reverse & 1) ? (int)(gridDim.x / H) - 1 - b_lin : b_lin, h = blockIdx.x % H;
+    const bool abl_nocompute = reverse & 2, abl_noload = reverse & 4;   // timing ablations (wrong results)
     const int D = H * DH;
     const size_t row_stride = (size_t)3 * D;
     const bf16_t* base = qkv + (size_t)b * T * row_stride + h * DH;
@@ -83,8 +90,11 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
             const int row = idx / CPR, c = idx - row * CPR;
             const int rr = row < T ? row : T - 1;        // clamp: always a valid address; rows >= T are not written
             const bf16_t* p = base + (size_t)rr * row_stride + c * 8;
-            kv[i] = *reinterpret_cast<const uint4*>(p + D);
-            vv[i] = *reinterpret_cast<const uint4*>(p + 2 * D);
+            kv[i] = make_uint4(0u, 0u, 0u, 0u); vv[i] = kv[i];
+            if (!abl_noload) {
+                kv[i] = *reinterpret_cast<const uint4*>(p + D);
+                vv[i] = *reinterpret_cast<const uint4*>(p + 2 * D);
+            }
         }
         // rows T .. NKEY-1: zeros (the bias row, if any, is filled after the barrier)
         for (int idx = T * CPR + tid; idx < NCHUNK; idx += NT) {
@@ -116,7 +126,12 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
     const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const char* v_base = v_lds + (4 * (g >> 1) + q4) * C::VROW + (16 * (g & 1) + 4 * p4) * 2;
 
-    for (int qt = wave; qt < nqt; qt += kAttnWaves) {
+    // 257 = 8*32 + 1: a ninth query tile with ONE valid row would make wave 0 run two tiles back to
+    // back (the critical path of the workgroup).  When the tile past the 8 main ones holds exactly one
+    // query, that query is instead processed cooperatively below: one key tile per wave.
+    const bool coop = (nqt == kAttnWaves + 1) && (T - kAttnWaves * 32 == 1);
+    const int nqt_main = coop ? kAttnWaves : nqt;
+    for (int qt = wave; qt < (abl_nocompute ? 0 : nqt_main); qt += kAttnWaves) {
         const int qrow = qt * 32 + r;
         if (qt != wave) {                                   // later tiles reload their queries
             const int qr = qrow < T ? qrow : T - 1;
@@ -243,6 +258,85 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
                 }
         }
     }
+
+    if (coop && !abl_nocompute) {
+        float* part = reinterpret_cast<float*>(smem + C::K_BYTES + C::V_BYTES);
+        const int xq = T - 1;                                  // the extra query row
+        const bf16_t* qp = base + (size_t)xq * row_stride + hh * 8;   // every column of the B operand = this query
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+        for (int kt = wave; kt < NKT; kt += kAttnWaves) {      // wave 0 also takes the last key tile
+            f32x16 sx = {};
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_base + kt * 32 * C::KROW + ks * 32);
+                sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sx, 0, 0, 0);
+            }
+            float mw = -INFINITY;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int key = kt * 32 + (reg & 3) + 8 * (reg >> 2) + hh4;
+                const float v = key < Lk ? sx[reg] : -INFINITY;
+                sx[reg] = v;
+                mw = fmaxf(mw, v);
+            }
+            mw = fmaxf(mw, __shfl_xor(mw, 32, 64));            // finite: every key tile holds a key < Lk
+            const float neg_m = -mw * scale_log2e;
+            float lw = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sx[reg], scale_log2e, neg_m));
+                sx[reg] = pv;
+                lw += pv;
+            }
+            lw += __shfl_xor(lw, 32, 64);
+            f32x16 ox[C::DT];
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) ox[dt] = f32x16{};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)sx[8 * st + j];
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt) {
+                    const char* vp = v_base + (kt * 32 + 16 * st) * C::VROW + dt * 64;
+                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp));
+                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp + 8 * C::VROW));
+                    const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    ox[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ox[dt], 0, 0, 0);
+                }
+            }
+            if (r == 0) {                                       // column 0: lanes 0 (hh=0) and 32 (hh=1)
+                float* dst = part + kt * C::X_FLOATS;
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int d0 = dt * 32 + 8 * gq + hh4;
+                        if (d0 < DH) {
+                            dst[d0 + 0] = ox[dt][4 * gq + 0]; dst[d0 + 1] = ox[dt][4 * gq + 1];
+                            dst[d0 + 2] = ox[dt][4 * gq + 2]; dst[d0 + 3] = ox[dt][4 * gq + 3];
+                        }
+                    }
+                if (hh == 0) { dst[DH] = mw; dst[DH + 1] = lw; }
+            }
+        }
+        __syncthreads();
+        if (tid < DH) {                                         // combine the NKT partials for output column tid
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) m = fmaxf(m, part[kt * C::X_FLOATS + DH]);
+            float acc = 0.f, l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const float w = __builtin_amdgcn_exp2f((part[kt * C::X_FLOATS + DH] - m) * scale_log2e);
+                acc = fmaf(part[kt * C::X_FLOATS + tid], w, acc);
+                l = fmaf(part[kt * C::X_FLOATS + DH + 1], w, l);
+            }
+            out[((size_t)b * T + xq) * D + h * DH + tid] = (bf16_t)(acc / l);
+        }
+    }
 }
 
 template <int DH, int NKT>
@@ -257,7 +351,7 @@ static int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int T, in
         attr_set = true;
     }
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
-    kern<<<batch * H, kAttnWaves * 64, C::LDS, st>>>(qkv, out, T, Lk, H, bias_k, bias_v, scale_log2e);
+    kern<<<batch * H, kAttnWaves * 64, C::LDS, st>>>(qkv, out, T, Lk, H, bias_k, bias_v, scale_log2e, g_attn_reverse);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
@@ -284,3 +378,5 @@ extern "C" int hmm_op_attention_bf16(const uint16_t* qkv_dev, uint16_t* out_dev,
     return attention_bf16(reinterpret_cast<const bf16_t*>(qkv_dev), reinterpret_cast<bf16_t*>(out_dev), batch, tokens,
                           heads, head_dim, bias_k_dev, bias_v_dev, static_cast<hipStream_t>(stream));
 }
+
+extern "C" void hmm_dev_set_attn_reverse(int v) { hmm::g_attn_reverse = v; }
