@@ -356,6 +356,107 @@ static int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int T, in
     return HMM_OK;
 }
 
+
+// Single-query attention for the LAST transformer block: the head consumes only token 0
+// (SelectElement(index=0)), so only the cls query of each image needs an attention output there.
+// One 256-thread workgroup per (image, head): thread j scores key j (a 2*dh-byte row of K straight
+// from HBM), block softmax through LDS, then the four waves accumulate disjoint key subsets of P.V.
+// VALU only: 2*Lk*dh MACs per (image, head); bound by the one read of K and V (HBM).
+template <int DH>
+__global__ __launch_bounds__(256) void attention_cls_kernel(const bf16_t* __restrict__ q_cls, const bf16_t* __restrict__ kv,
+                                                            bf16_t* __restrict__ out, int T, int Lk, int H,
+                                                            const float* __restrict__ bias_k,
+                                                            const float* __restrict__ bias_v, float scale) {
+    constexpr int MAXK = 320;
+    __shared__ float qs[DH];
+    __shared__ float p[MAXK];
+    __shared__ float red[8];
+    __shared__ float opart[4][DH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int D = H * DH;
+    const size_t kv_stride = (size_t)2 * D;
+    const bf16_t* kbase = kv + (size_t)b * T * kv_stride + h * DH;
+    if (tid < DH) qs[tid] = (float)q_cls[(size_t)b * D + h * DH + tid];
+    __syncthreads();
+
+    float local_max = -INFINITY;
+    for (int j = tid; j < Lk; j += 256) {
+        float s = 0.f;
+        if (j < T) {
+            const bf16_t* kr = kbase + (size_t)j * kv_stride;
+#pragma unroll
+            for (int c = 0; c < DH / 8; ++c) {
+                const bf16x8 kk = *reinterpret_cast<const bf16x8*>(kr + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s = fmaf(qs[c * 8 + e], (float)kk[e], s);
+            }
+        } else {
+            for (int d = 0; d < DH; ++d) s = fmaf(qs[d], (float)(bf16_t)bias_k[h * DH + d], s);
+        }
+        s *= scale;
+        p[j] = s;
+        local_max = fmaxf(local_max, s);
+    }
+    local_max = wave_max(local_max);
+    if (lane == 0) red[w] = local_max;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float local_sum = 0.f;
+    for (int j = tid; j < Lk; j += 256) {
+        const float e = __expf(p[j] - m);
+        p[j] = e;
+        local_sum += e;
+    }
+    local_sum = wave_sum(local_sum);
+    if (lane == 0) red[4 + w] = local_sum;
+    __syncthreads();
+    const float l = (red[4] + red[5]) + (red[6] + red[7]);
+
+    // P.V: wave w takes keys w, w+4, ...; lane takes d = lane (and lane + 64 when dh > 64)
+    const bf16_t* vbase = kbase + D;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int j = w; j < Lk; j += 4) {
+        const float pj = p[j];
+        float v0, v1 = 0.f;
+        if (j < T) {
+            const bf16_t* vr = vbase + (size_t)j * kv_stride;
+            v0 = (float)vr[lane];
+            if (DH > 64 && lane + 64 < DH) v1 = (float)vr[lane + 64];
+        } else {
+            v0 = (float)(bf16_t)bias_v[h * DH + lane];
+            if (DH > 64 && lane + 64 < DH) v1 = (float)(bf16_t)bias_v[h * DH + lane + 64];
+        }
+        acc0 = fmaf(pj, v0, acc0);
+        acc1 = fmaf(pj, v1, acc1);
+    }
+    if (lane < DH) opart[w][lane] = acc0;
+    if (DH > 64 && lane + 64 < DH) opart[w][lane + 64] = acc1;
+    __syncthreads();
+    if (tid < DH) {
+        const float o = (opart[0][tid] + opart[1][tid]) + (opart[2][tid] + opart[3][tid]);
+        out[(size_t)b * D + h * DH + tid] = (bf16_t)(o / l);
+    }
+}
+
+int attention_cls_bf16(const bf16_t* q_cls, const bf16_t* kv, bf16_t* out, int batch, int tokens, int heads,
+                       int head_dim, const float* bias_k, const float* bias_v, hipStream_t st) {
+    HMM_REQUIRE(q_cls && kv && out, HMM_E_INVALID, "attention_cls: null pointer");
+    const int Lk = tokens + (bias_k ? 1 : 0);
+    HMM_REQUIRE(Lk <= 320, HMM_E_INVALID, "attention_cls: %d keys exceed 320", Lk);
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    if (head_dim == 80)
+        attention_cls_kernel<80><<<batch * heads, 256, 0, st>>>(q_cls, kv, out, tokens, Lk, heads, bias_k, bias_v, scale);
+    else if (head_dim == 64)
+        attention_cls_kernel<64><<<batch * heads, 256, 0, st>>>(q_cls, kv, out, tokens, Lk, heads, bias_k, bias_v, scale);
+    else {
+        set_error("attention_cls: unsupported head_dim %d", head_dim);
+        return HMM_E_INVALID;
+    }
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+
 int attention_bf16(const bf16_t* qkv, bf16_t* out, int batch, int tokens, int heads, int head_dim,
                    const float* bias_k, const float* bias_v, hipStream_t st) {
     HMM_REQUIRE(qkv && out, HMM_E_INVALID, "attention: null pointer");

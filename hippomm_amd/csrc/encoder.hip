@@ -126,7 +126,7 @@ static void plan_params(hmm_encoder* e, std::vector<std::pair<void**, size_t>>& 
     e->arena_bytes = ab.cursor;
 }
 
-struct WsPlan { int n_img, R; size_t off_x, off_a, off_big, off_im2col, off_patch, off_hl, off_hv, total; };
+struct WsPlan { int n_img, R; size_t off_x, off_a, off_big, off_im2col, off_patch, off_hl, off_hv, off_xc, off_ac, off_qc, off_hc, total; };
 
 static WsPlan ws_plan(const hmm_encoder* e, int batch) {
     WsPlan p{};
@@ -145,6 +145,11 @@ static WsPlan ws_plan(const hmm_encoder* e, int batch) {
     cur = align_up(cur + (big > pre ? big : pre), 256);
     p.off_hl = cur;  cur = align_up(cur + (size_t)p.n_img * D * 2, 256);
     p.off_hv = cur;  cur = align_up(cur + (size_t)p.n_img * HMM_FEATURE_DIM * 4, 256);
+    // cls-only last block: residual rows, two bf16 row buffers, MLP hidden
+    p.off_xc = cur;  cur = align_up(cur + (size_t)p.n_img * D * 4, 256);
+    p.off_ac = cur;  cur = align_up(cur + (size_t)p.n_img * D * 2, 256);
+    p.off_qc = cur;  cur = align_up(cur + (size_t)p.n_img * D * 2, 256);
+    p.off_hc = cur;  cur = align_up(cur + (size_t)p.n_img * e->mlp * 2, 256);
     p.total = cur + 256;
     return p;
 }
@@ -268,19 +273,37 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const float* input_dev, int b
     HMM_TRY(gemm_bf16(im2col, e->patch_w, nullptr, patch, n_img * e->n_patches, D, e->patch_k_pad, HMM_EPI_F32, -1, st));
     HMM_TRY(launch_assemble_tokens(patch, e->cls, e->pos, e->stem_g, e->stem_b, 1e-5f, e->pre_g, e->pre_b, 1e-6f,
                                    x, n_img, T, D, st));
-    // transformer blocks
+    // transformer blocks.  The head reads only token 0 (SelectElement(index=0)), so the LAST block needs
+    // K/V for every token but Q, attention output, out-proj and the MLP for the cls row of each image only.
+    float* xc = reinterpret_cast<float*>(ws + p.off_xc);
+    bf16_t* ac = reinterpret_cast<bf16_t*>(ws + p.off_ac);
+    bf16_t* qc = reinterpret_cast<bf16_t*>(ws + p.off_qc);
+    bf16_t* hc = reinterpret_cast<bf16_t*>(ws + p.off_hc);
     for (int i = 0; i < e->depth; ++i) {
         const BlockW& w = e->blocks[i];
         HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
-        HMM_TRY(gemm_bf16(a, w.qkv_w, w.qkv_b, big, R, 3 * D, D, HMM_EPI_BIAS_BF16, -1, st));
-        HMM_TRY(attention_bf16(big, a, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st));
-        HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, -1, st));
-        HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
-        HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, -1, st));
-        HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, -1, st));
+        if (i + 1 < e->depth) {
+            HMM_TRY(gemm_bf16(a, w.qkv_w, w.qkv_b, big, R, 3 * D, D, HMM_EPI_BIAS_BF16, -1, st));
+            HMM_TRY(attention_bf16(big, a, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st));
+            HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, -1, st));
+            HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
+            HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, -1, st));
+            HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, -1, st));
+        } else {
+            // K|V projection of all rows (in_proj rows D..3D), Q projection of the cls rows (rows 0..D)
+            HMM_TRY(gemm_bf16(a, w.qkv_w + (size_t)D * D, w.qkv_b + D, big, R, 2 * D, D, HMM_EPI_BIAS_BF16, -1, st));
+            HMM_TRY(launch_gather_rows(a, (size_t)T * D * 2, ac, n_img, D * 2, st));
+            HMM_TRY(gemm_bf16(ac, w.qkv_w, w.qkv_b, qc, n_img, D, D, HMM_EPI_BIAS_BF16, -1, st));
+            HMM_TRY(attention_cls_bf16(qc, big, ac, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st));
+            HMM_TRY(launch_gather_rows(x, (size_t)T * D * 4, xc, n_img, D * 4, st));
+            HMM_TRY(gemm_bf16(ac, w.out_w, w.out_b, xc, n_img, D, D, HMM_EPI_BIAS_RESID_F32, -1, st));
+            HMM_TRY(launch_layernorm_bf16(xc, (size_t)D, w.ln2_g, w.ln2_b, ac, n_img, D, 1e-6f, st));
+            HMM_TRY(gemm_bf16(ac, w.fc1_w, w.fc1_b, hc, n_img, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, -1, st));
+            HMM_TRY(gemm_bf16(hc, w.fc2_w, w.fc2_b, xc, n_img, D, e->mlp, HMM_EPI_BIAS_RESID_F32, -1, st));
+        }
     }
     // head: LN on the cls rows -> Linear(D,1024) -> L2 normalise (x20, clip mean for audio)
-    HMM_TRY(launch_layernorm_bf16(x, (size_t)T * D, e->head_g, e->head_b, hl, n_img, D, 1e-6f, st));
+    HMM_TRY(launch_layernorm_bf16(xc, (size_t)D, e->head_g, e->head_b, hl, n_img, D, 1e-6f, st));
     HMM_TRY(gemm_bf16(hl, e->head_w, nullptr, hv, n_img, HMM_FEATURE_DIM, D, HMM_EPI_F32, -1, st));
     HMM_TRY(launch_l2norm_rows(hv, out_dev, batch, e->clips, e->log_scale, st));
 #undef HMM_TRY

@@ -164,6 +164,17 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
             make_float4(acc[j].x * inv, acc[j].y * inv, acc[j].z * inv, acc[j].w * inv);
 }
 
+// dst[i] = src[i * src_row_stride ... + D)   (cls rows of the token matrix; 16-B pieces)
+__global__ void gather_rows_kernel(const char* __restrict__ src, size_t src_row_stride_bytes, char* __restrict__ dst,
+                                   int n_rows, int row_bytes) {
+    const int per_row = row_bytes / 16;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_rows * per_row) return;
+    const int r = (int)(i / per_row), c = (int)(i % per_row);
+    *reinterpret_cast<uint4*>(dst + (size_t)r * row_bytes + c * 16) =
+        *reinterpret_cast<const uint4*>(src + (size_t)r * src_row_stride_bytes + c * 16);
+}
+
 // ---- weight packing -------------------------------------------------------------------------
 __global__ void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -225,6 +236,13 @@ int launch_im2col_audio(const float* mels, bf16_t* out, int n_clip, hipStream_t 
 }
 int launch_l2norm_rows(const float* v, float* out, int n_out, int clips, const float* log_scale, hipStream_t st) {
     l2norm_rows_kernel<<<(n_out + 3) / 4, 256, 0, st>>>(v, out, n_out, clips, log_scale);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+int launch_gather_rows(const void* src, size_t src_row_stride_bytes, void* dst, int n_rows, int row_bytes, hipStream_t st) {
+    const int64_t n = (int64_t)n_rows * (row_bytes / 16);
+    gather_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(static_cast<const char*>(src), src_row_stride_bytes,
+                                                                   static_cast<char*>(dst), n_rows, row_bytes);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }

@@ -777,6 +777,8 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         if (N % 256 != 0 || K % 128 != 0) return gemm_bf16(A, W, bias, C, M, N, K, epi, 2, st);
         const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
         const long tiles = (long)tiles_m * tiles_n;
+        // few 256x256 tiles (cls-only last block, head): 128x128 tiles put 4x more CUs to work
+        if (tiles < 128) return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
         int peel = 0;
         if (tiles > 256 && tiles % 256 != 0 && tiles % 256 <= 64)
             for (int p = 1; p <= 2 && !peel; ++p)
