@@ -319,6 +319,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     constexpr bool F_PARTIAL = F & 1, F_NOPRIO = F & 2, F_NOSTAG = F & 4, F_NODMA = F & 8, F_NOLDS = F & 16;
     constexpr bool F_NOEPI = F & 32;   // ablation: keep only one store per wave (results wrong)
     constexpr bool F_DEPHASE = F & 64; // first-round blocks start (blockIdx%8) x ~1.5 us apart
+    constexpr bool F_BAL = (F & 256) != 0; // opt-in: P4 prefetches the next K-tile's A_lo kh=0 fragments (LDS-read
+                                           // balancing; measured null, +20 VGPRs)
     constexpr int HALF = 16384, TILE = 4 * HALF;
     constexpr int H_ALO = 0, H_AHI = HALF, H_BLO = 2 * HALF, H_BHI = 3 * HALF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -336,8 +338,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
             for (int i = 0; i < xcd; ++i) __builtin_amdgcn_s_sleep(47);
     }
 
-    // staging sources: half-tile local row lr = (wave + 8j)*8 + (lane>>3), 16-B chunk (lane&7) un-swizzled
-    const bf16_t* src_alo[2]; const bf16_t* src_ahi[2]; const bf16_t* src_blo[2]; const bf16_t* src_bhi[2];
+    // staging sources as 32-bit element offsets from A / W (launcher guarantees M*K, N*K < 2^31):
+    // half-tile local row lr = (wave + 8j)*8 + (lane>>3), 16-B chunk (lane&7) un-swizzled
+    int src_alo[2], src_ahi[2], src_blo[2], src_bhi[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int lr = (wave + 8 * j) * 8 + (lane >> 3);
@@ -346,19 +349,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
         int g0 = m0 + arow, g1 = m0 + arow + 64;
         g0 = g0 < M ? g0 : M - 1;
         g1 = g1 < M ? g1 : M - 1;
-        src_alo[j] = A + (size_t)g0 * K + c * 8;
-        src_ahi[j] = A + (size_t)g1 * K + c * 8;
+        src_alo[j] = g0 * K + c * 8;
+        src_ahi[j] = g1 * K + c * 8;
         const int bcol = (lr >> 5) * 64 + (lr & 31);             // cols 0..31 of each wave-column
-        src_blo[j] = W + (size_t)(n0 + bcol) * K + c * 8;
-        src_bhi[j] = W + (size_t)(n0 + bcol + 32) * K + c * 8;
+        src_blo[j] = (n0 + bcol) * K + c * 8;
+        src_bhi[j] = (n0 + bcol + 32) * K + c * 8;
     }
-#define HMM_STAGE(src, kt, buf, half)                                                                       \
+#define HMM_STAGE2(base, src, kt, buf, half)                                                                \
     do {                                                                                                    \
-        __builtin_amdgcn_global_load_lds(HMM_GLB_PTR(src[0] + (kt) * 64),                                   \
+        __builtin_amdgcn_global_load_lds(HMM_GLB_PTR((base) + (ptrdiff_t)(src[0] + (kt) * 64)),             \
                                          HMM_LDS_PTR(smem + (buf) * TILE + (half) + wave * 1024), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds(HMM_GLB_PTR(src[1] + (kt) * 64),                                   \
+        __builtin_amdgcn_global_load_lds(HMM_GLB_PTR((base) + (ptrdiff_t)(src[1] + (kt) * 64)),             \
                                          HMM_LDS_PTR(smem + (buf) * TILE + (half) + (wave + 8) * 1024), 16, 0, 0); \
     } while (0)
+#define HMM_STAGE(src, kt, buf, half) HMM_STAGE_##src(kt, buf, half)
+#define HMM_STAGE_src_alo(kt, buf, half) HMM_STAGE2(A, src_alo, kt, buf, half)
+#define HMM_STAGE_src_ahi(kt, buf, half) HMM_STAGE2(A, src_ahi, kt, buf, half)
+#define HMM_STAGE_src_blo(kt, buf, half) HMM_STAGE2(W, src_blo, kt, buf, half)
+#define HMM_STAGE_src_bhi(kt, buf, half) HMM_STAGE2(W, src_bhi, kt, buf, half)
 
     // fragment read bases (bytes inside a half-tile)
     const int fsw = (lane & 15) >> 1;
@@ -372,6 +380,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[4][2], blo[2][2], bhi[2][2];
+    bf16x8 apre[4];                                           // next K-tile's A_lo, kh = 0 (read in P4)
 
 #define HMM_READ_A_KH(buf, half, kh, ck)                                                              \
     if (!F_NOLDS || t_first) {                                                                        \
@@ -388,6 +397,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
         acc[(mo) + mi][(no) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[ni][kh], af[mi][kh], \
                                                                             acc[(mo) + mi][(no) + ni], 0, 0, 0);
+#define HMM_MFMA_HALF_PRE(mo, no, bsrc)    /* kh = 0 with the prefetched A_lo fragments */             \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
+        acc[(mo) + mi][(no) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[ni][0], apre[mi],    \
+                                                                            acc[(mo) + mi][(no) + ni], 0, 0, 0);
+#define HMM_MFMA_QUAD_PRE(mo, no, bsrc)                                                               \
+    if constexpr (!F_NOPRIO) __builtin_amdgcn_s_setprio(1);                                           \
+    HMM_MFMA_HALF_PRE(mo, no, bsrc) HMM_MFMA_HALF(mo, no, bsrc, 1)                                     \
+    if constexpr (!F_NOPRIO) __builtin_amdgcn_s_setprio(0);
 #define HMM_MFMA_QUAD(mo, no, bsrc)                                                                   \
     if constexpr (!F_NOPRIO) __builtin_amdgcn_s_setprio(1);                                           \
     HMM_MFMA_HALF(mo, no, bsrc, 0) HMM_MFMA_HALF(mo, no, bsrc, 1)                                      \
@@ -423,6 +441,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
             if (!F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
             asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");                            \
             HMM_BAR() HMM_MFMA_QUAD_SPLIT(0, 0, blo) HMM_BAR()                            \
+        } else if constexpr (F_BAL) {                                                     \
+            if ((t) == 0) {                                                               \
+                _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                          \
+                    apre[mi] = *reinterpret_cast<const bf16x8*>(a_rd + (buf) * TILE + H_ALO + mi * 2048 + ck0); \
+            }                                                                             \
+            HMM_READ_A_KH(buf, H_ALO, 1, ck1) HMM_READ_B(blo, buf, H_BLO)                 \
+            if (!F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
+            HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD_PRE(0, 0, blo) HMM_BAR()                 \
         } else {                                                                          \
             HMM_READ_A(buf, H_ALO) HMM_READ_B(blo, buf, H_BLO)                            \
             if (!F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
@@ -431,18 +457,32 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
         /* P2: (lo,hi) */                                                                 \
         HMM_READ_B(bhi, buf, H_BHI)                                                       \
         if (!F_NODMA && (t) + 2 < KT) HMM_STAGE(src_alo, (t) + 2, buf, H_ALO);            \
-        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(0, 2, bhi) HMM_BAR()                         \
+        HMM_LGKM0(); HMM_BAR()                                                            \
+        if constexpr (F_BAL) { HMM_MFMA_QUAD_PRE(0, 2, bhi) } else { HMM_MFMA_QUAD(0, 2, bhi) } \
+        HMM_BAR()                                                                         \
         /* P3: (hi,hi) */                                                                 \
         HMM_READ_A(buf, H_AHI)                                                            \
         if (!F_NODMA && (t) + 2 < KT) HMM_STAGE(src_blo, (t) + 2, buf, H_BLO);            \
+        if constexpr (F_BAL) {                                                            \
+            /* (t+1).A_lo was staged 5 phases ago; younger: (t+1).B_lo, B_hi, A_hi, (t+2).A_lo, B_lo */ \
+            if ((t) + 2 < KT) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");           \
+            else if ((t) + 1 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       \
+        }                                                                                 \
         HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(4, 2, bhi) HMM_BAR()                         \
         /* P4: (hi,lo) */                                                                 \
+        if constexpr (F_BAL) {                                                            \
+            if ((t) + 1 < KT) {                                                           \
+                _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                          \
+                    apre[mi] = *reinterpret_cast<const bf16x8*>(a_rd + ((buf) ^ 1) * TILE + H_ALO + mi * 2048 + ck0); \
+            }                                                                             \
+        }                                                                                 \
         if (!F_NODMA && (t) + 2 < KT) {                                                   \
             HMM_STAGE(src_bhi, (t) + 2, buf, H_BHI);                                      \
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                              \
         } else {                                                                          \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              \
         }                                                                                 \
+        if constexpr (F_BAL) { HMM_LGKM0(); }                                             \
         HMM_BAR() HMM_MFMA_QUAD(4, 0, blo) HMM_BAR()                                      \
     }
 
@@ -453,10 +493,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     if (!F_NOSTAG && wm == 0) { HMM_BAR(); }                  // re-align the two wave groups
 #undef HMM_KTILE
 #undef HMM_STAGE
+#undef HMM_STAGE2
+#undef HMM_STAGE_src_alo
+#undef HMM_STAGE_src_ahi
+#undef HMM_STAGE_src_blo
+#undef HMM_STAGE_src_bhi
 #undef HMM_READ_A
 #undef HMM_READ_B
 #undef HMM_MFMA_QUAD
 #undef HMM_MFMA_QUAD_SPLIT
+#undef HMM_MFMA_QUAD_PRE
+#undef HMM_MFMA_HALF_PRE
 #undef HMM_MFMA_HALF
 #undef HMM_READ_A_KH
 #undef HMM_READ_B_KH
@@ -698,8 +745,14 @@ static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
     return HMM_OK;
 }
 
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                           int epi, hipStream_t st);
+
 static int launch_gemm_pp_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                               int epi, hipStream_t st) {
+    if ((size_t)M * K >= (1ull << 31) || (size_t)N * K >= (1ull << 31))       // 32-bit staging offsets
+        return launch_gemm_epi<256, 256, 2, 4>(A, W, bias, C, M, N, K, epi, st);
     switch (epi) {
         case HMM_EPI_BIAS_BF16:      return launch_gemm_pp<HMM_EPI_BIAS_BF16>(A, W, bias, C, M, N, K, st);
         case HMM_EPI_BIAS_GELU_BF16: return launch_gemm_pp<HMM_EPI_BIAS_GELU_BF16>(A, W, bias, C, M, N, K, st);
@@ -761,6 +814,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
             case 32: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 32>(A, W, bias, C, M, N, K, st);
             case 64: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 64>(A, W, bias, C, M, N, K, st);
             case 128: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 128>(A, W, bias, C, M, N, K, st);
+            case 256: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 256>(A, W, bias, C, M, N, K, st);
             case 56: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 56>(A, W, bias, C, M, N, K, st);
         }
     }

@@ -1,0 +1,69 @@
+"""GPU: the sharded path through RCCL (backend 'nccl') at world_size 1 -- the only size a 1-GPU box
+offers.  Exercises process-group init on the GPU, all_gather_into_tensor on device tensors and the
+HIP encode / select / scan legs inside hippomm_amd.sharding; world_size 2 logic is covered on CPU
+(tests/test_cpu_sharding.py, gloo)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+import recipes
+from oracle import imagebind_oracle as ib
+from oracle.consolidation_oracle import select_key_frames_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nccl_group():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield
+    dist.destroy_process_group()
+
+
+def test_rccl_all_gather_and_sharded_consolidation(nccl_group):
+    from hippomm_amd import sharding
+    from hippomm_amd.encoder import HipTower
+    # raw collective on device memory
+    t = torch.arange(8, dtype=torch.float32, device="cuda").reshape(2, 4)
+    out = torch.empty_like(t)
+    dist.all_gather_into_tensor(out, t)
+    assert torch.equal(out, t)
+
+    spec = ib.reduced(ib.VISION_HUGE, 1)
+    st = ib.synthetic_state(spec, seed=3, init="rich")
+    tower = HipTower("vision", st, depth=1)
+    frames = torch.randn(5, 3, 224, 224, generator=torch.Generator().manual_seed(2)).cuda()
+    feats, kept = sharding.consolidate_sharded(frames, tower, counts=[5])
+    assert feats.shape == (5, 1024)
+    want = select_key_frames_oracle(feats.cpu().numpy(), None, 0.9)
+    assert kept.cpu().tolist() == want.tolist()
+    # ragged path (size exchange) with identity "encoder" on clustered features
+    f = torch.from_numpy(recipes.clustered(50, 8, 0.2, seed=5)).cuda()
+    feats2, kept2 = sharding.consolidate_sharded(f, lambda x: x)
+    assert torch.equal(feats2, f)
+    assert kept2.cpu().tolist() == select_key_frames_oracle(f.cpu().numpy(), None, 0.9).tolist()
+
+
+def test_rccl_sharded_top_k(nccl_group):
+    from hippomm_amd import sharding
+    from hippomm_amd.vector_ops import FeatureStore
+    rng = np.random.default_rng(9)
+    store = rng.standard_normal((6000, 1024), dtype=np.float32)
+    q = torch.from_numpy(rng.standard_normal(1024, dtype=np.float32)).cuda()
+    fs = FeatureStore(store)
+    want_idx, want_sims = fs.search(q, 7)
+    idx, sims = sharding.sharded_top_k(q, 7, len(fs), 0, fs.search_keys_device)
+    assert idx.cpu().tolist() == want_idx.tolist()
+    np.testing.assert_array_equal(sims.cpu().numpy(), want_sims)
