@@ -33,8 +33,10 @@ __device__ __forceinline__ void row_layernorm(float4 (&x)[NV], const float* __re
 }
 
 // y_bf16[r] = LN(x_f32[r * in_stride ...])          (norm_1 / norm_2 / head LN on the cls rows)
+// <= 48 VGPRs on purpose: the ping-pong GEMM leaves 48 registers per SIMD lane free, so LayerNorm waves of
+// one half-batch can co-reside on a CU that is busy with a GEMM tile of the other half (two-stream forward).
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, size_t in_stride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void layernorm_bf16_kernel(const float* __restrict__ x, size_t in_stride,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              bf16_t* __restrict__ y, int rows, float eps) {
