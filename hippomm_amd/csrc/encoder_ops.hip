@@ -42,18 +42,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void laye
                                                              bf16_t* __restrict__ y, int rows, float eps) {
     constexpr int D = 256 * NV;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* src = x + (size_t)row * in_stride;
-    float4 v[NV];
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {   // grid-stride
+        const float* src = x + (size_t)row * in_stride;
+        float4 v[NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const float4*>(src + 4 * (64 * j + lane));
-    row_layernorm<NV>(v, gamma, beta, eps, lane);
-    bf16_t* dst = y + (size_t)row * D;
+        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const float4*>(src + 4 * (64 * j + lane));
+        row_layernorm<NV>(v, gamma, beta, eps, lane);
+        bf16_t* dst = y + (size_t)row * D;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        bf16x4 o = {(bf16_t)v[j].x, (bf16_t)v[j].y, (bf16_t)v[j].z, (bf16_t)v[j].w};
-        *reinterpret_cast<bf16x4*>(dst + 4 * (64 * j + lane)) = o;
+        for (int j = 0; j < NV; ++j) {
+            bf16x4 o = {(bf16_t)v[j].x, (bf16_t)v[j].y, (bf16_t)v[j].z, (bf16_t)v[j].w};
+            *reinterpret_cast<bf16x4*>(dst + 4 * (64 * j + lane)) = o;
+        }
     }
 }
 
@@ -200,12 +200,15 @@ __global__ void fold_conv3d_kernel(const float* __restrict__ w, bf16_t* __restri
     dst[i] = (bf16_t)v;
 }
 
+int g_ln_max_blocks = 0;   // tuning hook: > 0 caps the LayerNorm grid (persistent, grid-stride)
+
 // ---- launchers ------------------------------------------------------------------------------
 int launch_layernorm_bf16(const float* x, size_t in_stride, const float* g, const float* b, bf16_t* y,
                           int rows, int D, float eps, hipStream_t st) {
     HMM_REQUIRE(D == 768 || D == 1280, HMM_E_INVALID, "layernorm: D must be 768 or 1280, got %d", D);
     if (rows <= 0) return HMM_OK;
-    const int blocks = (rows + 3) / 4;
+    int blocks = (rows + 3) / 4;
+    if (g_ln_max_blocks > 0 && blocks > g_ln_max_blocks) blocks = g_ln_max_blocks;
     if (D == 768) layernorm_bf16_kernel<3><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps);
     else          layernorm_bf16_kernel<5><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps);
     HMM_LAUNCH_CHECK();
@@ -275,3 +278,5 @@ extern "C" int hmm_op_layernorm_bf16(const float* x_dev, const float* gamma_dev,
     return launch_layernorm_bf16(x_dev, (size_t)D, gamma_dev, beta_dev, reinterpret_cast<bf16_t*>(y_dev), rows, D, eps,
                                  static_cast<hipStream_t>(stream));
 }
+
+extern "C" void hmm_dev_set_ln_max_blocks(int n) { hmm::g_ln_max_blocks = n; }

@@ -529,6 +529,94 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 }
 
 
+// Small-slab variant of the transposed epilogue for the persistent kernel, whose K-tile buffers stay busy
+// with the next tile's DMA: one 16-row MFMA block row at a time through a per-wave slab of 2304 B
+// (bf16: 16 rows x 144 B) / 4096 B (fp32: 16 rows x 256 B, XOR-swizzled 16-B chunks), same store shape
+// as gemm_epilogue_lds (whole 128-B lines per wave-instruction).
+constexpr int kSlabBf16 = 2304, kSlabF32 = 4096;
+
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_slab(f32x4 (&acc)[8][4], const float* __restrict__ bias,
+                                                   void* __restrict__ Cout, int M, int N, int m_wave, int n_wave,
+                                                   char* slab, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    float4 bv[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+        bv[ni] = bias ? *reinterpret_cast<const float4*>(bias + n_wave + ni * 16 + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    if constexpr (EPI == HMM_EPI_BIAS_BF16 || EPI == HMM_EPI_BIAS_GELU_BF16) {
+        constexpr int RS = 144;
+        bf16_t* C = static_cast<bf16_t*>(Cout);
+        const int rsub = lane >> 3, chunk = lane & 7;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 v = acc[mi][ni];
+                v[0] += bv[ni].x; v[1] += bv[ni].y; v[2] += bv[ni].z; v[3] += bv[ni].w;
+                if constexpr (EPI == HMM_EPI_BIAS_GELU_BF16) {
+                    v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+                }
+                bf16x4 o4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                *reinterpret_cast<bf16x4*>(slab + fr * RS + (ni * 16 + 4 * fq) * 2) = o4;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            uint4 v2[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) v2[j] = *reinterpret_cast<const uint4*>(slab + (j * 8 + rsub) * RS + chunk * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = m_wave + mi * 16 + j * 8 + rsub;
+                if (m < M) *reinterpret_cast<uint4*>(C + (size_t)m * N + n_wave + chunk * 8) = v2[j];
+            }
+        }
+    } else {
+        float* C = static_cast<float*>(Cout);
+        const int rsub = lane >> 4, chunk = lane & 15;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            float4 xin[4];
+            if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m_wave + mi * 16 + j * 4 + rsub;
+                    xin[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m < M) xin[j] = *reinterpret_cast<const float4*>(C + (size_t)m * N + n_wave + chunk * 4);
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const f32x4 a = acc[mi][ni];
+                *reinterpret_cast<float4*>(slab + fr * 256 + (((ni * 4 + fq) ^ fr) & 15) * 16) =
+                    make_float4(a[0] + bv[ni].x, a[1] + bv[ni].y, a[2] + bv[ni].z, a[3] + bv[ni].w);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            float4 v4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = j * 4 + rsub;
+                v4[j] = *reinterpret_cast<const float4*>(slab + row * 256 + ((chunk ^ row) & 15) * 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m_wave + mi * 16 + j * 4 + rsub;
+                float4 v = v4[j];
+                if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
+                    v.x += xin[j].x; v.y += xin[j].y; v.z += xin[j].z; v.w += xin[j].w;
+                }
+                if (m < M) *reinterpret_cast<float4*>(C + (size_t)m * N + n_wave + chunk * 4) = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Persistent ping-pong variant.  Same 8-phase K-tile body as gemm_bf16_pp_kernel, but one workgroup
 // per CU walks a sequence of output tiles and the LDS-DMA stream never stops at a tile boundary: in
@@ -684,7 +772,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(
             HMM_KTILE(t + 1, 1)
         }
 
-        gemm_epilogue<EPI, 8, 4>(acc, bias, Cout, M, N, m0 + wm * 128 + (lane & 15), n0 + wn * 64 + 4 * (lane >> 4));
+        {
+            constexpr int SLAB = (EPI == HMM_EPI_BIAS_BF16 || EPI == HMM_EPI_BIAS_GELU_BF16) ? kSlabBf16 : kSlabF32;
+            gemm_epilogue_slab<EPI>(acc, bias, Cout, M, N, m0 + wm * 128, n0 + wn * 64, smem + 2 * TILE + wave * SLAB, lane);
+        }
         if (!more) break;
         tile = next; m0 = m0n; n0 = n0n;
         // re-base the pointers so that K-tile indices restart at 0 for the new tile
@@ -701,7 +792,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(
 
 template <int EPI>
 static int launch_gemm_pp2(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, hipStream_t st) {
-    constexpr int LDS = 2 * 4 * 16384;
+    constexpr int LDS = 2 * 4 * 16384 + 8 * ((EPI == HMM_EPI_BIAS_BF16 || EPI == HMM_EPI_BIAS_GELU_BF16) ? kSlabBf16 : kSlabF32);
     auto kern = gemm_bf16_pp2_kernel<EPI>;
     static bool attr_set = false;
     if (!attr_set) {
