@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void attention_cls_kernel(const bf16_t* __rest
     __shared__ float qs[DH];
     __shared__ float p[MAXK];
     __shared__ float red[8];
-    __shared__ float opart[4][DH];
+    __shared__ float opart[4 * (64 / (DH / 8))][DH];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int D = H * DH;
@@ -413,28 +413,36 @@ __global__ __launch_bounds__(256) void attention_cls_kernel(const bf16_t* __rest
     __syncthreads();
     const float l = (red[4] + red[5]) + (red[6] + red[7]);
 
-    // P.V: wave w takes keys w, w+4, ...; lane takes d = lane (and lane + 64 when dh > 64)
+    // P.V with 16-B loads: a lane owns one 8-wide d chunk (c) of one key slot; a wave covers SL keys per
+    // step, the 4 waves 4*SL.  Partial sums are reduced over slots and waves through LDS.
+    constexpr int CPR = DH / 8, SL = 64 / CPR;
+    const int slot = lane / CPR, c = lane - slot * CPR;
     const bf16_t* vbase = kbase + D;
-    float acc0 = 0.f, acc1 = 0.f;
-    for (int j = w; j < Lk; j += 4) {
-        const float pj = p[j];
-        float v0, v1 = 0.f;
-        if (j < T) {
-            const bf16_t* vr = vbase + (size_t)j * kv_stride;
-            v0 = (float)vr[lane];
-            if (DH > 64 && lane + 64 < DH) v1 = (float)vr[lane + 64];
-        } else {
-            v0 = (float)(bf16_t)bias_v[h * DH + lane];
-            if (DH > 64 && lane + 64 < DH) v1 = (float)(bf16_t)bias_v[h * DH + lane + 64];
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (slot < SL) {
+#pragma unroll 4
+        for (int j = w * SL + slot; j < Lk; j += 4 * SL) {
+            const float pj = p[j];
+            bf16x8 vv;
+            if (j < T) {
+                vv = *reinterpret_cast<const bf16x8*>(vbase + (size_t)j * kv_stride + c * 8);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[e] = (bf16_t)bias_v[h * DH + c * 8 + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, (float)vv[e], acc[e]);
         }
-        acc0 = fmaf(pj, v0, acc0);
-        acc1 = fmaf(pj, v1, acc1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) opart[w * SL + slot][c * 8 + e] = acc[e];
     }
-    if (lane < DH) opart[w][lane] = acc0;
-    if (DH > 64 && lane + 64 < DH) opart[w][lane + 64] = acc1;
     __syncthreads();
     if (tid < DH) {
-        const float o = (opart[0][tid] + opart[1][tid]) + (opart[2][tid] + opart[3][tid]);
+        float o = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4 * SL; ++i) o += opart[i][tid];
         out[(size_t)b * D + h * DH + tid] = (bf16_t)(o / l);
     }
 }
