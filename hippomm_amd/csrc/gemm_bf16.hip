@@ -300,10 +300,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
 //   phase 3 (hi,hi)          reads A_hi, reuses the B_hi registers -> A_hi dead after P3
 //   phase 4 (hi,lo)          reads nothing (B_lo registers kept)
 // so every phase can re-stage exactly one dead half-tile (2 x global_load_lds_dwordx4 per wave):
-//   P1: (t+1).A_hi   P2: (t+2).A_lo   P3: (t+2).B_lo   P4: (t+2).B_hi
-// i.e. the LDS-DMA stream runs ~1.75 K-tiles ahead of the MFMAs and is never drained in the loop:
-// the only wait is a counted vmcnt(6) in P4, which retires K-tile t+1 while the three youngest
-// half-tiles (of t+2) stay in flight.  Waves 4-7 run one barrier behind waves 0-3, so on every
+//   P2: (t+2).A_lo   P3: (t+2).B_lo   P4: (t+2).B_hi + (t+2).A_hi      (P1, the read-heavy phase, stages nothing)
+// i.e. the LDS-DMA stream runs 1-2 K-tiles ahead of the MFMAs and is never drained in the loop: the only
+// wait is a counted vmcnt(8) in P4, which retires K-tile t+1 (staged >= 4 phases earlier) while the four
+// youngest half-tiles (of t+2) stay in flight.  Waves 4-7 run one barrier behind waves 0-3, so on every
 // SIMD one wave issues its 16-MFMA burst while its partner does its LDS reads and DMA issue.
 // Hazards: a half-tile is re-staged only in a phase after the one whose reads were retired by
 // lgkmcnt(0) *before* that phase's first barrier (WAR); staged data is read only in a phase after
@@ -319,6 +319,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     constexpr bool F_PARTIAL = F & 1, F_NOPRIO = F & 2, F_NOSTAG = F & 4, F_NODMA = F & 8, F_NOLDS = F & 16;
     constexpr bool F_NOEPI = F & 32;   // ablation: keep only one store per wave (results wrong)
     constexpr bool F_DEPHASE = F & 64; // first-round blocks start (blockIdx%8) x ~1.5 us apart
+    constexpr bool F_EARLY = !(F & 512);     // default: stage (t+2).A_hi in P4(t) (with B_hi) instead of (t+1).A_hi in P1(t):
+                                             // every half-tile then has >= 4 phases of lead before the counted wait (+1-2 %)
     constexpr bool F_BAL = (F & 256) != 0; // opt-in: P4 prefetches the next K-tile's A_lo kh=0 fragments (LDS-read
                                            // balancing; measured null, +20 VGPRs)
     constexpr int HALF = 16384, TILE = 4 * HALF;
@@ -427,7 +429,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     HMM_STAGE(src_alo, 0, 0, H_ALO); HMM_STAGE(src_blo, 0, 0, H_BLO);
     HMM_STAGE(src_bhi, 0, 0, H_BHI); HMM_STAGE(src_ahi, 0, 0, H_AHI);
     HMM_STAGE(src_alo, 1, 1, H_ALO); HMM_STAGE(src_blo, 1, 1, H_BLO); HMM_STAGE(src_bhi, 1, 1, H_BHI);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (F_EARLY) {
+        HMM_STAGE(src_ahi, 1, 1, H_AHI);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
     HMM_BAR();
     if (!F_NOSTAG && wm == 1) { HMM_BAR(); }                  // waves 4-7 run one barrier behind
 
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
         if constexpr (F_PARTIAL) {                                                        \
             HMM_READ_A_KH(buf, H_ALO, 0, ck0) HMM_READ_B_KH(blo, buf, H_BLO, 0, ck0)      \
             HMM_READ_A_KH(buf, H_ALO, 1, ck1) HMM_READ_B_KH(blo, buf, H_BLO, 1, ck1)      \
-            if (!F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
+            if (!F_EARLY && !F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
             asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");                            \
             HMM_BAR() HMM_MFMA_QUAD_SPLIT(0, 0, blo) HMM_BAR()                            \
         } else if constexpr (F_BAL) {                                                     \
@@ -447,11 +454,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
                     apre[mi] = *reinterpret_cast<const bf16x8*>(a_rd + (buf) * TILE + H_ALO + mi * 2048 + ck0); \
             }                                                                             \
             HMM_READ_A_KH(buf, H_ALO, 1, ck1) HMM_READ_B(blo, buf, H_BLO)                 \
-            if (!F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
+            if (!F_EARLY && !F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
             HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD_PRE(0, 0, blo) HMM_BAR()                 \
         } else {                                                                          \
             HMM_READ_A(buf, H_ALO) HMM_READ_B(blo, buf, H_BLO)                            \
-            if (!F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
+            if (!F_EARLY && !F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
             HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(0, 0, blo) HMM_BAR()                     \
         }                                                                                 \
         /* P2: (lo,hi) */                                                                 \
@@ -478,7 +485,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
         }                                                                                 \
         if (!F_NODMA && (t) + 2 < KT) {                                                   \
             HMM_STAGE(src_bhi, (t) + 2, buf, H_BHI);                                      \
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                              \
+            if constexpr (F_EARLY) {                                                      \
+                HMM_STAGE(src_ahi, (t) + 2, buf, H_AHI);                                  \
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                          \
+            } else {                                                                      \
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                          \
+            }                                                                             \
         } else {                                                                          \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              \
         }                                                                                 \
@@ -906,6 +918,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
             case 64: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 64>(A, W, bias, C, M, N, K, st);
             case 128: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 128>(A, W, bias, C, M, N, K, st);
             case 256: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 256>(A, W, bias, C, M, N, K, st);
+            case 512: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 512>(A, W, bias, C, M, N, K, st);
             case 56: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 56>(A, W, bias, C, M, N, K, st);
         }
     }
