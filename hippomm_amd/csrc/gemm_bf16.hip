@@ -321,6 +321,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     constexpr bool F_DEPHASE = F & 64; // first-round blocks start (blockIdx%8) x ~1.5 us apart
     constexpr bool F_EARLY = !(F & 512);     // default: stage (t+2).A_hi in P4(t) (with B_hi) instead of (t+1).A_hi in P1(t):
                                              // every half-tile then has >= 4 phases of lead before the counted wait (+1-2 %)
+    // residual epilogue: touch the tile's fp32 residual lines with 4-byte LDS-DMA loads during K-tiles 0..3 so that
+    // the epilogue's read-modify-write finds them in L2 / Infinity Cache instead of bursting HBM reads with its writes
+    // (opt-in experiment, measured NEGATIVE: out-proj 282 -> 320 us -- 64 scattered line requests per touch)
+    constexpr bool F_XPF = (EPI == HMM_EPI_BIAS_RESID_F32) && F_EARLY && (F & 1024);
     constexpr bool F_BAL = (F & 256) != 0; // opt-in: P4 prefetches the next K-tile's A_lo kh=0 fragments (LDS-read
                                            // balancing; measured null, +20 VGPRs)
     constexpr int HALF = 16384, TILE = 4 * HALF;
@@ -382,6 +386,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[4][2], blo[2][2], bhi[2][2];
+    // residual-prefetch addresses: the 256x256 fp32 tile is 2048 lines of 128 B; thread tid touches lines tid + 512*i
+    const float* xpf_base = static_cast<const float*>(Cout);
+    int xpf_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int line = (int)threadIdx.x + 512 * i;
+        int row = m0 + (line >> 3);
+        row = row < M ? row : M - 1;
+        xpf_off[i] = F_XPF ? row * N + n0 + (line & 7) * 32 : 0;
+    }
     bf16x8 apre[4];                                           // next K-tile's A_lo, kh = 0 (read in P4)
 
 #define HMM_READ_A_KH(buf, half, kh, ck)                                                              \
@@ -487,7 +501,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
             HMM_STAGE(src_bhi, (t) + 2, buf, H_BHI);                                      \
             if constexpr (F_EARLY) {                                                      \
                 HMM_STAGE(src_ahi, (t) + 2, buf, H_AHI);                                  \
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                          \
+                if (F_XPF && (t) < 4) {                                                   \
+                    __builtin_amdgcn_global_load_lds(HMM_GLB_PTR(xpf_base + (size_t)xpf_off[(t) & 3]), \
+                                                     HMM_LDS_PTR(smem + 8 * kEpiSlab + wave * 256), 4, 0, 0); \
+                    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                      \
+                } else {                                                                  \
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                      \
+                }                                                                         \
             } else {                                                                      \
                 asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                          \
             }                                                                             \
@@ -834,7 +854,7 @@ static int launch_gemm_pp2_epi(const bf16_t* A, const bf16_t* W, const float* bi
 
 template <int EPI, int F = 0>
 static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, hipStream_t st) {
-    constexpr int LDS = 8 * kEpiSlab > 2 * 4 * 16384 ? 8 * kEpiSlab : 2 * 4 * 16384;
+    constexpr int LDS = (8 * kEpiSlab > 2 * 4 * 16384 ? 8 * kEpiSlab : 2 * 4 * 16384) + 8 * 256;   // + residual-prefetch sink
     auto kern = gemm_bf16_pp_kernel<EPI, F>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -906,6 +926,11 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
     if (variant < 0) variant = g_gemm_default_variant;
     if (variant == 3 && (N % 256 != 0 || K % 128 != 0)) variant = 2;
     if (variant == 2 && N % 256 != 0) variant = 1;
+    if (variant == 2024) {                                                               // A/B: 4 WITH the residual-prefetch experiment
+        if (epi == HMM_EPI_BIAS_RESID_F32 && N % 256 == 0 && K % 128 == 0 && (long)((M + 255) / 256) * (N / 256) >= 128)
+            return launch_gemm_pp<HMM_EPI_BIAS_RESID_F32, 1024>(A, W, bias, C, M, N, K, st);
+        variant = 4;
+    }
     if (variant >= 100 && epi == HMM_EPI_BIAS_BF16 && N % 256 == 0 && K % 128 == 0) {   // experiment builds
         switch (variant - 100) {
             case 1:  return launch_gemm_pp<HMM_EPI_BIAS_BF16, 1>(A, W, bias, C, M, N, K, st);
