@@ -59,7 +59,11 @@ def test_golden_vectors(name):
 
 @pytest.mark.parametrize("n,k", [(1, 1), (1, 5), (2, 5), (63, 5), (4096, 32), (4097, 32), (8191, 7),
                                  (20000, 1), (20000, 5), (20000, 100), (20000, 1024), (9000, 2000),
-                                 (5000, 5000), (70001, 32)])
+                                 (5000, 5000), (70001, 32),
+                                 # fused scan: one-kernel finish (k*k <= 4096) vs chunk passes (k in 65..128),
+                                 # few scan blocks, a single straggler row, sims-buffer path (k > 128)
+                                 (4097, 1), (4098, 64), (4104, 65), (12345, 128), (12345, 129), (300001, 64),
+                                 (300001, 100)])
 def test_matches_oracle(n, k):
     from hippomm_amd.vector_ops import top_k_cosine_similarity
     rng = np.random.default_rng(n * 31 + k)
