@@ -331,6 +331,50 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(const uint64_t* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Per-event feature_search.  The reference loops over events in Python and scans each event's
+// matrix with k=5 (hippocampal_memory.py:3143-3153, :3294-3304).  Here all events live concatenated in one
+// resident store with a row-offset table: one streaming pass computes every similarity, then one workgroup
+// per event selects that event's top-k (indices are rows WITHIN the event) under the same total order.
+// Events larger than a chunk are folded in pieces, carrying the running best k.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void segment_topk_kernel(const float* __restrict__ sims,
+                                                            const int64_t* __restrict__ seg_off, int k,
+                                                            int64_t* __restrict__ idx_out, float* __restrict__ sim_out,
+                                                            int32_t* __restrict__ n_out) {
+    __shared__ uint64_t s[kChunk];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int64_t lo = seg_off[e], hi = seg_off[e + 1];
+    const int64_t n = hi - lo;
+    const int k_out = (int)(n < k ? (n > 0 ? n : 0) : k);
+    int have = 0;                                              // best keys carried from earlier pieces, at s[0..have)
+    int64_t base = 0;
+    do {
+        const int64_t left = n - base;
+        const int take = (int)(left < (int64_t)(kChunk - have) ? left : (int64_t)(kChunk - have));
+        const int total = have + take;
+        const int n2 = pow2_at_least(total, 64);
+        for (int t = have + tid; t < n2; t += 1024) {
+            uint64_t key = 0ull;
+            if (t < total) {
+                const int64_t r = base + (t - have);
+                key = ((uint64_t)order_bits(sims[lo + r]) << 32) | (uint64_t)(uint32_t)r;
+            }
+            s[t] = key;
+        }
+        __syncthreads();
+        bitonic_sort_desc_rt(s, n2);
+        have = total < k ? total : k;
+        base += take;
+    } while (base < n);
+    if (tid == 0) n_out[e] = k_out;
+    for (int t = tid; t < k; t += 1024) {
+        const bool ok = t < k_out;
+        idx_out[(int64_t)e * k + t] = ok ? (int64_t)(s[t] & 0xFFFFFFFFull) : -1;
+        sim_out[(int64_t)e * k + t] = ok ? order_bits_inverse((uint32_t)(s[t] >> 32)) : 0.0f;
+    }
+}
+
 struct ScanPlan {
     int64_t n; int k_eff; bool full_sort; int64_t n_pad;
     size_t off_sims, off_a, off_b, total;
@@ -532,6 +576,39 @@ extern "C" int hmm_dev_scan_topk_only(const float* store_dev, int64_t n_rows, co
     if (blocks > kScanBlocks) blocks = kScanBlocks;
     scan_topk_kernel<true><<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
         reinterpret_cast<const float4*>(store_dev), n_rows, reinterpret_cast<const float4*>(query_dev), k, cand_dev);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+
+extern "C" size_t hmm_cosine_topk_segmented_workspace_bytes(int64_t n_rows, int n_segments, int k) {
+    if (n_rows < 0 || n_segments < 1 || k < 1) return 0;
+    return align_up((size_t)(n_rows > 0 ? n_rows : 1) * sizeof(float), 256) + 256;
+}
+
+extern "C" int hmm_cosine_topk_segmented(const float* store_dev, int64_t n_rows, int dim, const float* query_dev,
+                                         const int64_t* seg_offsets_dev, int n_segments, int k,
+                                         int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
+                                         void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream) {
+    HMM_REQUIRE(dim == HMM_FEATURE_DIM, HMM_E_INVALID, "cosine_topk_segmented: dim must be %d, got %d", HMM_FEATURE_DIM, dim);
+    HMM_REQUIRE(n_rows >= 0 && n_rows < (int64_t)0xFFFFFFFFll, HMM_E_INVALID, "cosine_topk_segmented: n_rows out of range");
+    HMM_REQUIRE(n_segments >= 1 && k >= 1 && k <= kFastK, HMM_E_INVALID,
+                "cosine_topk_segmented: need n_segments >= 1 and 1 <= k <= %d", kFastK);
+    HMM_REQUIRE(query_dev && seg_offsets_dev && idx_out_dev && sim_out_dev && n_out_dev && workspace_dev, HMM_E_INVALID,
+                "cosine_topk_segmented: null pointer");
+    HMM_REQUIRE(n_rows == 0 || store_dev, HMM_E_INVALID, "cosine_topk_segmented: null store");
+    HMM_REQUIRE(workspace_bytes >= hmm_cosine_topk_segmented_workspace_bytes(n_rows, n_segments, k), HMM_E_WORKSPACE,
+                "cosine_topk_segmented: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* sims = static_cast<float*>(workspace_dev);
+    if (n_rows > 0) {
+        int64_t waves_needed = (n_rows + 1) / 2;
+        int blocks = (int)((waves_needed + 3) / 4);
+        if (blocks > kScanBlocks) blocks = kScanBlocks;
+        scan_sims_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store_dev), n_rows,
+                                                       reinterpret_cast<const float4*>(query_dev), sims);
+        HMM_LAUNCH_CHECK();
+    }
+    segment_topk_kernel<<<n_segments, 1024, 0, st>>>(sims, seg_offsets_dev, k, idx_out_dev, sim_out_dev, n_out_dev);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }

@@ -81,6 +81,25 @@ class FeatureStore:
                    "hmm_cosine_topk_keys")
         return keys
 
+    def search_segments_device(self, query: torch.Tensor, seg_offsets: torch.Tensor, k: int):
+        """Per-event top-k in one pass.  seg_offsets: int64 CUDA tensor (E+1,), row offsets of the events inside
+        this store.  Returns CUDA tensors idx (E,k) int64 rows within each event (-1 padded), sims (E,k) fp32,
+        counts (E,) int32 = min(k, n_e)."""
+        lib = _lib.load()
+        dev = self.rows.device
+        E = seg_offsets.numel() - 1
+        need = lib.hmm_cosine_topk_segmented_workspace_bytes(len(self), E, k)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        idx = torch.empty(E, k, dtype=torch.int64, device=dev)
+        sims = torch.empty(E, k, dtype=torch.float32, device=dev)
+        counts = torch.empty(E, dtype=torch.int32, device=dev)
+        _lib.check(lib.hmm_cosine_topk_segmented(self.rows.data_ptr(), len(self), FEATURE_DIM, query.data_ptr(),
+                                                 seg_offsets.data_ptr(), E, k, idx.data_ptr(), sims.data_ptr(),
+                                                 counts.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                                 _lib.stream_ptr()), "hmm_cosine_topk_segmented")
+        return idx, sims, counts
+
     def search(self, query, k: int) -> Tuple[np.ndarray, np.ndarray]:
         q = _query_to_device(query, self.rows.device)
         idx, sims = self.search_device(q, k)
@@ -132,3 +151,29 @@ def top_k_cosine_similarity(
     if a_is64 or store.source_dtype == np.float64:
         sims = sims.astype(np.float64)
     return idx.astype(np.int64, copy=False), sims
+
+
+class EventStore(FeatureStore):
+    """All events' feature matrices of one modality concatenated in HBM, with their row offsets: what
+    ``QARecallSystem._find_relevant_*_segments`` iterates over (hippocampal_memory.py:3143, :3294)."""
+
+    def __init__(self, event_features, device=None):
+        mats = [np.ascontiguousarray(np.asarray(f).reshape(-1, FEATURE_DIM), dtype=np.float32) for f in event_features]
+        self.lengths = [m.shape[0] for m in mats]
+        rows = np.concatenate(mats, axis=0) if mats and sum(self.lengths) else np.zeros((0, FEATURE_DIM), np.float32)
+        dev = device or _lib.require_gpu()
+        if rows.shape[0] == 0:
+            self.source_dtype = np.dtype(np.float32)
+            self.rows = torch.zeros(0, FEATURE_DIM, dtype=torch.float32, device=dev)
+            self._ws = None
+        else:
+            super().__init__(rows, dev)
+        self.offsets = torch.tensor(np.concatenate([[0], np.cumsum(self.lengths)]), dtype=torch.int64, device=dev)
+
+    def top_k_per_event(self, query, k: int = 5):
+        """[(indices int64[k_e], sims float32[k_e]) for every event], each exactly what
+        ``top_k_cosine_similarity(query, event_features, k)`` returns for that event."""
+        q = _query_to_device(query, self.rows.device)
+        idx, sims, counts = self.search_segments_device(q, self.offsets, int(k))
+        idx, sims, counts = idx.cpu().numpy(), sims.cpu().numpy(), counts.cpu().numpy()
+        return [(idx[e, :counts[e]].astype(np.int64), sims[e, :counts[e]]) for e in range(len(self.lengths))]

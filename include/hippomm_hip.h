@@ -73,6 +73,18 @@ int    hmm_topk_merge_keys(const uint64_t* keys_dev /* [n_shards][k] */, int n_s
                            int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
                            hmm_stream_t stream);
 
+/* Per-event feature_search in one pass.  Replaces the Python loop over events that calls
+ * top_k_cosine_similarity(query, event.features[...], k=5) once per event
+ * (hippomm/core/hippocampal_memory.py:3143-3153, :3294-3304).  store_dev is the concatenation of the
+ * events' (n_e,1024) matrices, seg_offsets_dev int64[n_segments+1] their row offsets (non-decreasing,
+ * last = n_rows).  Per event e: n_out[e] = min(k, n_e); idx_out[e*k ..] rows WITHIN the event (best first,
+ * -1 padded), sim_out[e*k ..] (0 padded).  Same similarity and total order as hmm_cosine_topk. k <= 1024. */
+size_t hmm_cosine_topk_segmented_workspace_bytes(int64_t n_rows, int n_segments, int k);
+int    hmm_cosine_topk_segmented(const float* store_dev, int64_t n_rows, int dim, const float* query_dev,
+                                 const int64_t* seg_offsets_dev, int n_segments, int k,
+                                 int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
+                                 void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Consolidation similarity.  Replaces HippocampalMemory._select_key_frames(features, times,
  * similarity_threshold=0.9) (hippomm/core/hippocampal_memory.py:944-967; caller :855).
