@@ -1,0 +1,173 @@
+"""memory_store event files: fast path beside the reference's JSON.
+
+The reference stores every consolidated event as ``events/<video_id>/<event_id>.json`` written by
+``json.dump(event.to_dict(), f, indent=2)`` (hippomm/core/hippocampal_memory.py:110-133, :331-335) and reads
+it back with ``json.load`` + ``np.array(list)`` (:369-395): one Python float per line, ~20 bytes of text per
+stored fp32, float64 arrays after loading.  That file format is the contract with the unmodified
+``load_theta_event`` and is kept byte for byte.  What this module adds:
+
+* ``save_event``     writes the same JSON **plus** an fp32 ``.npy`` sidecar per feature matrix and a manifest
+                     holding the JSON's size and mtime;
+* ``load_event_features``  returns the fp32 matrices from the sidecars when they are fresh (same size+mtime
+                     as recorded), else parses the JSON once and (re)writes the sidecars.  Values are
+                     identical either way: the JSON holds fp32 values printed as doubles, and
+                     ``float32(float64(text))`` round-trips them exactly;
+* ``build_event_store``  reads ``event_index.json`` (:338-346) and returns an ``EventStore`` with one modality's
+                     matrices of all events resident in HBM, ready for ``top_k_per_event``.
+
+Nothing here touches the GPU except ``build_event_store``.
+"""
+from __future__ import annotations
+
+import json
+import os
+from pathlib import Path
+from typing import Any, Dict, Iterable, List, Mapping, Optional, Tuple
+
+import numpy as np
+
+SIDECAR_VERSION = 1
+_EVENT_KEYS = ("frames", "frame_times", "frame_captions", "audio_times", "audio_transcription",
+               "holistic_audio_transcription", "summary", "start_time", "end_time")
+
+
+def event_to_dict(event: Any) -> Dict[str, Any]:
+    """The dict ``ThetaEvent.to_dict`` builds (:110-133), from a ThetaEvent-like object or a mapping with the
+    same fields.  Keys ending in ``_times`` inside ``features`` move to ``feature_times``; arrays become lists."""
+    get = (lambda k, d=None: event.get(k, d)) if isinstance(event, Mapping) else (lambda k, d=None: getattr(event, k, d))
+    features_dict, times_dict = {}, {}
+    for modality, features in get("features").items():
+        (times_dict if modality.endswith("_times") else features_dict)[modality] = np.asarray(features).tolist()
+    return {
+        "features": features_dict, "feature_times": times_dict,
+        "frames": get("frames"), "frame_times": get("frame_times"), "frame_captions": get("frame_captions"),
+        "audio_times": get("audio_times"), "audio_transcription": get("audio_transcription"),
+        "holistic_audio_transcription": get("holistic_audio_transcription"), "summary": get("summary"),
+        "start_time": get("start_time"), "end_time": get("end_time"),
+    }
+
+
+def event_json_text(event: Any) -> str:
+    """Exactly the text ``save_theta_event`` writes (:334-335)."""
+    d = event.to_dict() if hasattr(event, "to_dict") else event_to_dict(event)
+    return json.dumps(d, indent=2)
+
+
+def _sidecar_paths(json_path: Path, modality: str) -> Tuple[Path, Path]:
+    stem = json_path.with_suffix("")
+    return Path(f"{stem}.{modality}.f32.npy"), Path(f"{stem}.sidecar.json")
+
+
+def _write_sidecars(json_path: Path, features: Mapping[str, np.ndarray]) -> None:
+    st = json_path.stat()
+    shapes = {}
+    for modality, arr in features.items():
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        npy, _ = _sidecar_paths(json_path, modality)
+        tmp = npy.with_suffix(".tmp.npy")
+        np.save(tmp, a)
+        os.replace(tmp, npy)
+        shapes[modality] = list(a.shape)
+    _, manifest = _sidecar_paths(json_path, "x")
+    tmp = manifest.with_suffix(".tmp")
+    tmp.write_text(json.dumps({"version": SIDECAR_VERSION, "json_size": st.st_size, "json_mtime_ns": st.st_mtime_ns,
+                               "modalities": shapes}))
+    os.replace(tmp, manifest)
+
+
+def save_event(event: Any, json_path, write_sidecars: bool = True) -> Path:
+    """Write the reference's JSON (byte-identical) and, optionally, the fp32 sidecars next to it."""
+    json_path = Path(json_path)
+    json_path.parent.mkdir(parents=True, exist_ok=True)
+    json_path.write_text(event_json_text(event))
+    if write_sidecars:
+        feats = event.features if hasattr(event, "features") else event["features"]
+        _write_sidecars(json_path, {m: f for m, f in feats.items() if not m.endswith("_times")})
+    return json_path
+
+
+def _fresh_manifest(json_path: Path) -> Optional[dict]:
+    _, manifest = _sidecar_paths(json_path, "x")
+    try:
+        m = json.loads(manifest.read_text())
+        st = json_path.stat()
+        if m.get("version") == SIDECAR_VERSION and m["json_size"] == st.st_size and m["json_mtime_ns"] == st.st_mtime_ns:
+            return m
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def parse_event_features(json_path) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
+    """Slow path, the reference's own reading rules (:369-408): new format with ``feature_times``, and the old
+    format where a modality maps to ``{'features': ..., 'times': ...}``.  Features come back as fp32."""
+    data = json.loads(Path(json_path).read_text())
+    feats, times = {}, {}
+    if "feature_times" in data:
+        for modality, t in data["feature_times"].items():
+            times[modality] = np.array(t)
+        for modality, f in data["features"].items():
+            feats[modality] = np.array(f)
+    else:
+        for modality, d in data["features"].items():
+            if isinstance(d, dict):
+                if "features" in d:
+                    feats[modality] = np.array(d["features"])
+                if "times" in d:
+                    times[modality] = np.array(d["times"])
+            else:
+                feats[modality] = np.array(d)
+    out = {}
+    for modality, a in feats.items():
+        if a.ndim > 1 and a.shape[1] != 1024 and a.shape[0] == 1024:      # the reference's transpose fix-up (:413-417)
+            a = a.T
+        out[modality] = np.ascontiguousarray(a, dtype=np.float32)
+    return out, times
+
+
+def load_event_features(json_path, use_sidecar: bool = True, write_sidecar: bool = True,
+                        mmap: bool = False) -> Dict[str, np.ndarray]:
+    """fp32 feature matrices of one event; sidecar when fresh, JSON otherwise."""
+    json_path = Path(json_path)
+    if use_sidecar:
+        m = _fresh_manifest(json_path)
+        if m is not None:
+            try:
+                return {mod: np.load(_sidecar_paths(json_path, mod)[0], mmap_mode="r" if mmap else None)
+                        for mod in m["modalities"]}
+            except OSError:
+                pass
+    feats, _ = parse_event_features(json_path)
+    if write_sidecar:
+        try:
+            _write_sidecars(json_path, feats)
+        except OSError:
+            pass                                    # read-only store: keep working from the JSON
+    return feats
+
+
+def iter_event_files(memory_store_dir) -> Iterable[Tuple[str, Path]]:
+    """(event_id, json path) in index order, from ``<base>/event_index.json`` (:338-346)."""
+    base = Path(memory_store_dir)
+    index = json.loads((base / "event_index.json").read_text())
+    for event_id, info in index.items():
+        p = Path(info["file_path"])
+        if not p.is_absolute() and not p.exists():
+            p = base / "events" / info["video_id"] / f"{event_id}.json"
+        yield event_id, p
+
+
+def build_event_store(memory_store_dir, modality: str = "vision", device=None):
+    """All events' ``modality`` matrices of a memory_store, resident in HBM.  Returns (EventStore, event_ids);
+    events that lack the modality or whose width is not 1024 get an empty segment (the reference skips them
+    with a warning, :3135-3137)."""
+    from .vector_ops import EventStore
+    ids, mats = [], []
+    for event_id, path in iter_event_files(memory_store_dir):
+        feats = load_event_features(path)
+        a = feats.get(modality)
+        if a is None or a.ndim != 2 or a.shape[1] != 1024:
+            a = np.zeros((0, 1024), np.float32)
+        ids.append(event_id)
+        mats.append(a)
+    return EventStore(mats, device), ids

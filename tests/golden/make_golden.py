@@ -112,6 +112,11 @@ def main():
             "min_evaluated_margin": (None if not np.isfinite(margin) else margin),
         }
     (HERE / "select_golden.json").write_text(json.dumps(sel, indent=1))
+    # memory_store event JSON, exactly as save_theta_event writes it (hippocampal_memory.py:110-133, :331-335)
+    from hippomm.core.hippocampal_memory import ThetaEvent
+    ev = ThetaEvent(**recipes.event_case())
+    (HERE / "event_golden.json").write_text(json.dumps(ev.to_dict(), indent=2))
+    print("event golden:", (HERE / "event_golden.json").stat().st_size, "bytes")
     for name, c in sel["cases"].items():
         print(f"select {name:24s} n={c['n']:5d} kept={len(c['kept']):4d} margin={c['min_evaluated_margin']}")
     for name, c in scan["cases"].items():

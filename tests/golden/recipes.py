@@ -123,3 +123,24 @@ def select_case(name: str):
 SELECT_CASES = ["n1", "n2", "n3", "n32_clusters6", "n257_clusters40", "n3600_clusters600",
                 "n64_revisit", "n40_all_distinct", "n40_all_same", "n24_duplicates",
                 "n20_near_threshold", "n12_zero_row"]
+
+
+# ------------------------------------------------------------- memory_store event (8f-2)
+def event_case():
+    """A small consolidated event: 3 vision rows (all frames), 2 audio rows, kept frames 0 and 2."""
+    rng = np.random.default_rng(2024)
+    vision = rng.standard_normal((3, D)).astype(np.float32)
+    vision /= np.linalg.norm(vision, axis=1, keepdims=True)
+    audio = (20.0 * rng.standard_normal((2, D)) / np.sqrt(D)).astype(np.float32)
+    return dict(
+        features={"vision": vision, "vision_times": np.array([0.0, 1.0, 2.5]),
+                  "audio": audio, "audio_times": np.array([0.0, 10.0])},
+        feature_times=None,
+        frames=["frames/vid/t_0000/frame_000000.jpg", "frames/vid/t_0002/frame_000075.jpg"],
+        frame_times=[0.0, 2.5],
+        frame_captions=["a person opens a door", "the same person sits down"],
+        audio_times=[0.0, 10.0],
+        audio_transcription=[{"text": "hello there", "start": 0.2, "end": 1.1}],
+        holistic_audio_transcription=[{"text": "hello there", "start": 0.2, "end": 1.1}],
+        summary="Someone enters a room and sits down.",
+        start_time=0.0, end_time=12.5)

@@ -1,0 +1,80 @@
+"""CPU: memory_store event fast path against the JSON the reference's own ThetaEvent.to_dict
+produced (tests/golden/event_golden.json, written by tests/golden/make_golden.py)."""
+import json
+import os
+import time
+from pathlib import Path
+
+import numpy as np
+
+import recipes
+from hippomm_amd import event_store as es
+
+GOLD = Path(__file__).resolve().parent / "golden" / "event_golden.json"
+
+
+def test_writer_is_byte_identical_to_the_reference():
+    case = recipes.event_case()
+    assert es.event_json_text(case) == GOLD.read_text()
+    d = es.event_to_dict(case)
+    assert list(d) == ["features", "feature_times", "frames", "frame_times", "frame_captions", "audio_times",
+                       "audio_transcription", "holistic_audio_transcription", "summary", "start_time", "end_time"]
+    assert set(d["features"]) == {"vision", "audio"} and set(d["feature_times"]) == {"vision_times", "audio_times"}
+
+
+def test_json_round_trip_is_exact_in_fp32():
+    case = recipes.event_case()
+    feats, times = es.parse_event_features(GOLD)
+    for m in ("vision", "audio"):
+        assert feats[m].dtype == np.float32
+        np.testing.assert_array_equal(feats[m], case["features"][m])      # fp32 -> text -> fp32 is lossless
+    np.testing.assert_array_equal(times["vision_times"], case["features"]["vision_times"])
+
+
+def test_sidecar_is_used_when_fresh_and_rebuilt_when_stale(tmp_path):
+    case = recipes.event_case()
+    p = es.save_event(case, tmp_path / "events" / "vid" / "vid_0.json")
+    assert p.read_text() == GOLD.read_text()
+    npy = tmp_path / "events" / "vid" / "vid_0.vision.f32.npy"
+    assert npy.exists() and (tmp_path / "events" / "vid" / "vid_0.sidecar.json").exists()
+    # fresh: served from the sidecar (prove it by corrupting the sidecar content only)
+    marker = case["features"]["vision"].copy(); marker[0, 0] = 42.0
+    np.save(npy, marker)
+    assert es.load_event_features(p)["vision"][0, 0] == 42.0
+    # the JSON is rewritten by the reference (different mtime/size): sidecar is stale -> parsed again and repaired
+    case2 = recipes.event_case(); case2["summary"] = "edited"
+    time.sleep(0.01)
+    p.write_text(es.event_json_text(case2))
+    got = es.load_event_features(p)
+    np.testing.assert_array_equal(got["vision"], case["features"]["vision"])
+    np.testing.assert_array_equal(np.load(npy), case["features"]["vision"])
+    # no sidecar at all (a store written by the unmodified reference)
+    for f in p.parent.glob("vid_0.*"):
+        if f != p:
+            f.unlink()
+    np.testing.assert_array_equal(es.load_event_features(p, write_sidecar=False)["audio"], case["features"]["audio"])
+    assert not npy.exists()
+
+
+def test_old_event_format_and_transposed_features(tmp_path):
+    v = recipes.event_case()["features"]["vision"]
+    old = {"features": {"vision": {"features": v.tolist(), "times": [0.0, 1.0, 2.5]}, "audio": v.T.tolist()}}
+    p = tmp_path / "old.json"
+    p.write_text(json.dumps(old))
+    feats, times = es.parse_event_features(p)
+    np.testing.assert_array_equal(feats["vision"], v)
+    np.testing.assert_array_equal(feats["audio"], v)                       # (1024,3) is transposed back, :413-417
+    assert times["vision"].tolist() == [0.0, 1.0, 2.5]
+
+
+def test_index_iteration(tmp_path):
+    case = recipes.event_case()
+    base = tmp_path / "memory_store"
+    index = {}
+    for i in range(3):
+        eid = f"vid_{i * 1000}"
+        p = es.save_event(case, base / "events" / "vid" / f"{eid}.json", write_sidecars=(i != 1))
+        index[eid] = {"video_id": "vid", "start_time": float(i), "end_time": float(i + 1), "file_path": str(p)}
+    (base / "event_index.json").write_text(json.dumps(index, indent=2))
+    got = list(es.iter_event_files(base))
+    assert [g[0] for g in got] == list(index) and all(g[1].exists() for g in got)

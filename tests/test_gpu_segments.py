@@ -53,3 +53,34 @@ def test_segmented_equals_single_scan_on_one_segment():
     off = torch.tensor([0, 20000], dtype=torch.int64, device="cuda")
     sidx, ssims, cnt = fs.search_segments_device(q, off, 32)
     assert int(cnt[0]) == 32 and torch.equal(sidx[0], idx) and torch.equal(ssims[0], sims)
+
+
+def test_build_event_store_from_memory_store_dir(tmp_path):
+    """memory_store/ on disk (reference layout) -> EventStore in HBM -> per-event top-5 == oracle per event."""
+    import json
+    import recipes
+    from hippomm_amd import event_store as es
+    base = tmp_path / "memory_store"
+    rng = np.random.default_rng(12)
+    index, mats = {}, []
+    for i, n in enumerate([7, 300, 1, 50]):
+        case = recipes.event_case()
+        v = rng.standard_normal((n, 1024)).astype(np.float32)
+        case["features"] = {"vision": v, "vision_times": np.arange(n, dtype=np.float64)}
+        if i == 2:
+            case["features"] = {"audio": v, "audio_times": np.arange(n, dtype=np.float64)}     # no vision in this event
+        eid = f"vid_{i * 1000}"
+        p = es.save_event(case, base / "events" / "vid" / f"{eid}.json", write_sidecars=(i % 2 == 0))
+        index[eid] = {"video_id": "vid", "start_time": float(i), "end_time": float(i + 1), "file_path": str(p)}
+        mats.append(v if i != 2 else np.zeros((0, 1024), np.float32))
+    (base / "event_index.json").write_text(json.dumps(index, indent=2))
+    store, ids = es.build_event_store(base, "vision")
+    assert ids == list(index) and store.lengths == [7, 300, 0, 50]
+    q = rng.standard_normal(1024).astype(np.float32)
+    for ev, (idx, sims) in zip(mats, store.top_k_per_event(q, 5)):
+        if ev.shape[0] == 0:
+            assert len(idx) == 0
+            continue
+        want_idx, want_sims = top_k_cosine_similarity_oracle(q, ev, 5)
+        assert idx.tolist() == want_idx.tolist()
+        np.testing.assert_allclose(sims, want_sims, rtol=0, atol=SIM_ATOL)
