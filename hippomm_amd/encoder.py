@@ -236,9 +236,9 @@ class ImageBind(nn.Module):
         """Raw inputs -> model tensors per modality (reference :48-114).  Errors are logged and
         the modality is skipped, as in the reference (:110-112).
 
-        vision: list of image paths / PIL images (opened by path via ``.filename``, :83-86), resized
-        (bicubic, short side 224), centre-cropped and CLIP-normalised; or an already preprocessed
-        (B,3,224,224) tensor.  audio: a preprocessed (B,3,1,128,204) log-mel tensor; wav paths need
+        vision: list of image paths / PIL images (opened by path via ``.filename``, :83-86): decoded on the host,
+        then resized (Pillow-identical bicubic, short side 224), centre-cropped and CLIP-normalised on the GPU
+        (hippomm_amd/preprocess.py); or an already preprocessed (B,3,224,224) tensor.  audio: a preprocessed (B,3,1,128,204) log-mel tensor; wav paths need
         the kaldi filterbank front end (not built) and are rejected."""
         transformed = {}
         for modality in modalities:
@@ -250,7 +250,8 @@ class ImageBind(nn.Module):
                     transformed[modality] = value.to(self.device)
                 elif modality == ModalityType.VISION:
                     paths = [img if isinstance(img, str) else img.filename for img in value]
-                    transformed[modality] = load_and_transform_vision_data(paths, self.device)
+                    from .preprocess import load_and_transform_vision_data_device      # decode on host, rest on GPU
+                    transformed[modality] = load_and_transform_vision_data_device(paths, self.device)
                 elif modality == ModalityType.AUDIO:
                     if not all(isinstance(x, str) for x in value):
                         raise ValueError("Audio inputs must be file paths. Direct tensor/array inputs are not supported.")

@@ -137,6 +137,22 @@ int  hmm_encoder_forward(hmm_encoder* enc, const float* input_dev, int batch, fl
 double hmm_encoder_flops(const hmm_encoder* enc, int batch);
 
 /* ------------------------------------------------------------------------------------------
+ * Device-side vision preprocessing.  Replaces, for already decoded frames, the transform chain of
+ * imagebind.data.load_and_transform_vision_data (torchvision Resize(224, BICUBIC) -> CenterCrop(224) ->
+ * ToTensor -> Normalize(CLIP mean/std) [upstream, recalled]) used at hippomm/models/foundation_models.py:87-90.
+ * Bit-identical to Pillow's resize: two passes, 8-bit intermediate, 22-bit fixed-point coefficients computed by
+ * the host (hippomm_amd/preprocess.py) for the 224 centre-cropped columns (kh/bh) and rows (kv/bv):
+ *   k*_dev int32[224][ksize], b*_dev int32[224][2] = (first tap, tap count); rows [row_first,row_last) of the
+ *   input are the ones the vertical taps touch.  frames_dev uint8 (batch,in_h,in_w,3) RGB; out (batch,3,224,224).
+ * ---------------------------------------------------------------------------------------- */
+size_t hmm_preprocess_vision_workspace_bytes(int batch, int rows_needed);
+int    hmm_preprocess_vision_u8(const uint8_t* frames_dev, int batch, int in_h, int in_w,
+                                const int32_t* kh_dev, const int32_t* bh_dev, int ksize_h,
+                                const int32_t* kv_dev, const int32_t* bv_dev, int ksize_v,
+                                int row_first, int row_last, float* out_dev,
+                                void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Building blocks of the encoder, exported so that each kernel is parity-tested on its own
  * against a torch fp32 reference of the same op (tests/test_gpu_ops.py) and timed on its own
  * (bench.py roofline).  bf16 tensors are raw uint16 bit patterns in device memory.
