@@ -62,6 +62,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
     const int b_lin = blockIdx.x / H;
     const int b = (reverse & 1) ? (int)(gridDim.x / H) - 1 - b_lin : b_lin, h = blockIdx.x % H;
     const bool abl_nocompute = reverse & 2, abl_noload = reverse & 4;   // timing ablations (wrong results)
+    const bool causal = reverse & 256;                                  // text tower: key j visible to query i iff j <= i
     const int D = H * DH;
     const size_t row_stride = (size_t)3 * D;
     const bf16_t* base = qkv + (size_t)b * T * row_stride + h * DH;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
     // 257 = 8*32 + 1: a ninth query tile with ONE valid row would make wave 0 run two tiles back to
     // back (the critical path of the workgroup).  When the tile past the 8 main ones holds exactly one
     // query, that query is instead processed cooperatively below: one key tile per wave.
-    const bool coop = (nqt == kAttnWaves + 1) && (T - kAttnWaves * 32 == 1);
+    const bool coop = (nqt == kAttnWaves + 1) && (T - kAttnWaves * 32 == 1) && !causal;
     const int nqt_main = coop ? kAttnWaves : nqt;
     for (int qt = wave; qt < (abl_nocompute ? 0 : nqt_main); qt += kAttnWaves) {
         const int qrow = qt * 32 + r;
@@ -173,8 +174,9 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
             for (int i = 0; i < CHT; ++i) {
                 const int kt = ch * CHT + i;
                 if (kt < NKT) {
-                    if ((kt + 1) * 32 > Lk) {
-                        const int rel = Lk - kt * 32 - hh4;          // key masked iff (reg&3)+8*(reg>>2) >= rel
+                    if ((kt + 1) * 32 > Lk || causal) {
+                        const int lim = causal ? (qrow + 1 < Lk ? qrow + 1 : Lk) : Lk;   // first invisible key
+                        const int rel = lim - kt * 32 - hh4;         // key masked iff (reg&3)+8*(reg>>2) >= rel
 #define HMM_MASK1(REG, KC)                                                                         \
     {                                                                                              \
         float v = s[i][REG];                                                                       \
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
 
 template <int DH, int NKT>
 static int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int T, int Lk, int H,
-                            const float* bias_k, const float* bias_v, hipStream_t st) {
+                            const float* bias_k, const float* bias_v, hipStream_t st, bool causal) {
     using C = AttnCfg<DH, NKT>;
     auto kern = attention_kernel<DH, NKT>;
     static bool attr_set = false;
@@ -351,7 +353,8 @@ static int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int T, in
         attr_set = true;
     }
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
-    kern<<<batch * H, kAttnWaves * 64, C::LDS, st>>>(qkv, out, T, Lk, H, bias_k, bias_v, scale_log2e, g_attn_reverse);
+    kern<<<batch * H, kAttnWaves * 64, C::LDS, st>>>(qkv, out, T, Lk, H, bias_k, bias_v, scale_log2e,
+                                                     g_attn_reverse | (causal ? 256 : 0));
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
@@ -466,13 +469,14 @@ int attention_cls_bf16(const bf16_t* q_cls, const bf16_t* kv, bf16_t* out, int b
 }
 
 int attention_bf16(const bf16_t* qkv, bf16_t* out, int batch, int tokens, int heads, int head_dim,
-                   const float* bias_k, const float* bias_v, hipStream_t st) {
+                   const float* bias_k, const float* bias_v, hipStream_t st, bool causal) {
     HMM_REQUIRE(qkv && out, HMM_E_INVALID, "attention: null pointer");
     HMM_REQUIRE((bias_k == nullptr) == (bias_v == nullptr), HMM_E_INVALID, "attention: bias_k and bias_v go together");
     HMM_REQUIRE(batch >= 1 && tokens >= 1 && heads >= 1, HMM_E_INVALID, "attention: bad shape");
     const int Lk = tokens + (bias_k ? 1 : 0);
-    if (head_dim == 80 && Lk <= 288) return launch_attention<80, 9>(qkv, out, batch, tokens, Lk, heads, bias_k, bias_v, st);
-    if (head_dim == 64 && Lk <= 256) return launch_attention<64, 8>(qkv, out, batch, tokens, Lk, heads, bias_k, bias_v, st);
+    HMM_REQUIRE(!(causal && bias_k), HMM_E_INVALID, "attention: causal mask with bias_kv is not defined here");
+    if (head_dim == 80 && Lk <= 288) return launch_attention<80, 9>(qkv, out, batch, tokens, Lk, heads, bias_k, bias_v, st, causal);
+    if (head_dim == 64 && Lk <= 256) return launch_attention<64, 8>(qkv, out, batch, tokens, Lk, heads, bias_k, bias_v, st, causal);
     set_error("attention: unsupported head_dim=%d / keys=%d (built: 80 x <=288 keys, 64 x <=256 keys)", head_dim, Lk);
     return HMM_E_INVALID;
 }
@@ -489,3 +493,10 @@ extern "C" int hmm_op_attention_bf16(const uint16_t* qkv_dev, uint16_t* out_dev,
 }
 
 extern "C" void hmm_dev_set_attn_reverse(int v) { hmm::g_attn_reverse = v; }
+
+// causal variant of hmm_op_attention_bf16 (text tower); testing hook
+extern "C" int hmm_dev_attention_causal_bf16(const uint16_t* qkv_dev, uint16_t* out_dev, int batch, int tokens, int heads,
+                                             int head_dim, hmm_stream_t stream) {
+    return attention_bf16(reinterpret_cast<const bf16_t*>(qkv_dev), reinterpret_cast<bf16_t*>(out_dev), batch, tokens,
+                          heads, head_dim, nullptr, nullptr, static_cast<hipStream_t>(stream), true);
+}

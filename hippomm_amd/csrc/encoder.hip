@@ -52,7 +52,8 @@ struct hmm_encoder {
     size_t arena_bytes = 0;
     std::unordered_map<std::string, ParamSlot> slots;
     // resolved pointers
-    float *cls, *pos, *stem_g, *stem_b, *pre_g, *pre_b, *head_g, *head_b, *log_scale;
+    float *cls, *pos, *stem_g, *stem_b, *pre_g, *pre_b, *head_g, *head_b, *log_scale, *tok_emb;
+    int vocab = 0;
     bf16_t *patch_w, *head_w;
     std::vector<BlockW> blocks;
 };
@@ -72,7 +73,7 @@ struct ArenaBuilder {
 
 static void plan_params(hmm_encoder* e, std::vector<std::pair<void**, size_t>>& fix) {
     ArenaBuilder ab{e};
-    const std::string m = e->tower == HMM_TOWER_VISION ? "vision" : "audio";
+    const std::string m = e->tower == HMM_TOWER_VISION ? "vision" : (e->tower == HMM_TOWER_AUDIO ? "audio" : "text");
     const std::string pp = "modality_preprocessors." + m + ".";
     const std::string tr = "modality_trunks." + m + ".";
     const std::string hd = "modality_heads." + m + ".";
@@ -83,9 +84,15 @@ static void plan_params(hmm_encoder* e, std::vector<std::pair<void**, size_t>>& 
     auto b16 = [&](const std::string& key, int64_t n, bf16_t** dst) {
         fix.push_back({reinterpret_cast<void**>(dst), ab.add(key, n, PACK_BF16, (size_t)n * 2)});
     };
-    f32(pp + "cls_token", D, &e->cls);
-    f32(pp + "pos_embedding_helper.pos_embed", (int64_t)e->T * D, &e->pos);
-    if (e->tower == HMM_TOWER_VISION) {
+    if (e->tower == HMM_TOWER_TEXT) {
+        f32(pp + "token_embedding.weight", (int64_t)e->vocab * D, &e->tok_emb);
+        f32(pp + "pos_embed", (int64_t)e->T * D, &e->pos);
+    } else {
+        f32(pp + "cls_token", D, &e->cls);
+        f32(pp + "pos_embedding_helper.pos_embed", (int64_t)e->T * D, &e->pos);
+    }
+    if (e->tower == HMM_TOWER_TEXT) {
+    } else if (e->tower == HMM_TOWER_VISION) {
         fix.push_back({reinterpret_cast<void**>(&e->patch_w),
                        ab.add(pp + "rgbt_stem.proj.1.weight", (int64_t)D * 3 * 2 * 14 * 14, PACK_FOLD_CONV3D,
                               (size_t)D * e->patch_k_pad * 2)});
@@ -121,14 +128,20 @@ static void plan_params(hmm_encoder* e, std::vector<std::pair<void**, size_t>>& 
         b16(b + "mlp.fc2.weight", (int64_t)D * e->mlp, &w.fc2_w);
         f32(b + "mlp.fc2.bias", D, &w.fc2_b);
     }
-    f32(hd + "0.weight", D, &e->head_g);
-    f32(hd + "0.bias", D, &e->head_b);
-    b16(hd + "2.weight", (int64_t)HMM_FEATURE_DIM * D, &e->head_w);
-    if (e->scaled) f32("modality_postprocessors.audio.1.log_logit_scale", 1, &e->log_scale);
+    if (e->tower == HMM_TOWER_TEXT) {
+        f32(hd + "proj.0.weight", D, &e->head_g);
+        f32(hd + "proj.0.bias", D, &e->head_b);
+        b16(hd + "proj.1.weight", (int64_t)HMM_FEATURE_DIM * D, &e->head_w);
+    } else {
+        f32(hd + "0.weight", D, &e->head_g);
+        f32(hd + "0.bias", D, &e->head_b);
+        b16(hd + "2.weight", (int64_t)HMM_FEATURE_DIM * D, &e->head_w);
+    }
+    if (e->scaled) f32("modality_postprocessors." + m + ".1.log_logit_scale", 1, &e->log_scale);
     e->arena_bytes = ab.cursor;
 }
 
-struct WsPlan { int n_img, R; size_t off_x, off_a, off_big, off_im2col, off_patch, off_hl, off_hv, off_xc, off_ac, off_qc, off_hc, total; };
+struct WsPlan { int n_img, R; size_t off_x, off_a, off_big, off_im2col, off_patch, off_hl, off_hv, off_xc, off_ac, off_qc, off_hc, off_sel, total; };
 
 static WsPlan ws_plan(const hmm_encoder* e, int batch) {
     WsPlan p{};
@@ -152,6 +165,7 @@ static WsPlan ws_plan(const hmm_encoder* e, int batch) {
     p.off_ac = cur;  cur = align_up(cur + (size_t)p.n_img * D * 2, 256);
     p.off_qc = cur;  cur = align_up(cur + (size_t)p.n_img * D * 2, 256);
     p.off_hc = cur;  cur = align_up(cur + (size_t)p.n_img * e->mlp * 2, 256);
+    p.off_sel = cur; cur = align_up(cur + (size_t)p.n_img * 4, 256);
     p.total = cur + 256;
     return p;
 }
@@ -160,21 +174,27 @@ static WsPlan ws_plan(const hmm_encoder* e, int batch) {
 
 extern "C" int hmm_encoder_create(hmm_encoder** out, int tower, int depth) {
     HMM_REQUIRE(out, HMM_E_INVALID, "encoder_create: null out");
-    HMM_REQUIRE(tower == HMM_TOWER_VISION || tower == HMM_TOWER_AUDIO, HMM_E_INVALID, "encoder_create: tower %d", tower);
+    HMM_REQUIRE(tower == HMM_TOWER_VISION || tower == HMM_TOWER_AUDIO || tower == HMM_TOWER_TEXT, HMM_E_INVALID,
+                "encoder_create: tower %d", tower);
     hmm_encoder* e = new hmm_encoder();
     e->tower = tower;
     if (tower == HMM_TOWER_VISION) {
         e->D = 1280; e->depth = 32; e->heads = 16; e->mlp = 5120; e->n_patches = 256;
         e->patch_k = 588; e->patch_k_pad = 640; e->clips = 1;
         e->pre_ln = true; e->stem_ln = false; e->bias_kv = false; e->scaled = false;
-    } else {
+    } else if (tower == HMM_TOWER_AUDIO) {
         e->D = 768; e->depth = 12; e->heads = 12; e->mlp = 3072; e->n_patches = 228;
         e->patch_k = 256; e->patch_k_pad = 256; e->clips = 3;
         e->pre_ln = false; e->stem_ln = true; e->bias_kv = true; e->scaled = true;
+    } else {                                           // CLIP-style text tower: 77 token positions, causal
+        e->D = 1024; e->depth = 24; e->heads = 16; e->mlp = 4096; e->n_patches = 76;
+        e->patch_k = 0; e->patch_k_pad = 64; e->clips = 1; e->vocab = 49408;
+        e->pre_ln = false; e->stem_ln = false; e->bias_kv = false; e->scaled = true;
     }
     if (depth > 0) e->depth = depth;
     e->T = e->n_patches + 1;
     e->cls = e->pos = e->stem_g = e->stem_b = e->pre_g = e->pre_b = e->head_g = e->head_b = e->log_scale = nullptr;
+    e->tok_emb = nullptr;
     e->patch_w = e->head_w = nullptr;
     std::vector<std::pair<void**, size_t>> fix;
     plan_params(e, fix);
@@ -255,7 +275,7 @@ extern "C" double hmm_encoder_flops(const hmm_encoder* e, int batch) {
     if (!e || batch < 1) return 0.0;
     const double D = e->D, T = e->T, H = e->mlp, Lk = e->T + (e->bias_kv ? 1 : 0);
     // un-folded patch projection, as the reference computes it (vision: both temporal taps)
-    const double patch_k = e->tower == HMM_TOWER_VISION ? 2.0 * e->patch_k : e->patch_k;
+    const double patch_k = e->tower == HMM_TOWER_VISION ? 2.0 * e->patch_k : e->patch_k;    // text: 0 (embedding lookup)
     double macs = e->n_patches * patch_k * D;                        // patch projection
     macs += e->depth * (T * D * (3 * D + D + 2 * H) + 2 * T * Lk * D);   // projections + MLP + QK^T + PV
     macs += D * HMM_FEATURE_DIM;                                     // head
@@ -265,7 +285,7 @@ extern "C" double hmm_encoder_flops(const hmm_encoder* e, int batch) {
 namespace hmm {
 
 struct Chain {                 // one (half-)batch travelling through the tower on one stream
-    const float* input; float* out; char* ws; WsPlan p; hipStream_t st; int batch;
+    const void* input; float* out; char* ws; WsPlan p; hipStream_t st; int batch;
 };
 
 #define HMM_TRY(call) do { int _rc = (call); if (_rc != HMM_OK) return _rc; } while (0)
@@ -276,8 +296,14 @@ static int chain_tokens(hmm_encoder* e, const Chain& c) {
     bf16_t* im2col = reinterpret_cast<bf16_t*>(c.ws + p.off_im2col);
     float* patch = reinterpret_cast<float*>(c.ws + p.off_patch);
     const int D = e->D, n_img = p.n_img;
-    if (e->tower == HMM_TOWER_VISION) HMM_TRY(launch_im2col_vision(c.input, im2col, n_img, c.st));
-    else                              HMM_TRY(launch_im2col_audio(c.input, im2col, n_img, c.st));
+    if (e->tower == HMM_TOWER_TEXT) {                  // ids (B,77) int64 -> token embedding + positions; EOS rows
+        const int64_t* ids = static_cast<const int64_t*>(c.input);
+        HMM_TRY(launch_embed_tokens(ids, e->tok_emb, e->pos, x, n_img * e->T, e->T, e->vocab, c.st));
+        HMM_TRY(launch_select_eos(ids, reinterpret_cast<int32_t*>(c.ws + p.off_sel), n_img, e->T, c.st));
+        return HMM_OK;
+    }
+    if (e->tower == HMM_TOWER_VISION) HMM_TRY(launch_im2col_vision(static_cast<const float*>(c.input), im2col, n_img, c.st));
+    else                              HMM_TRY(launch_im2col_audio(static_cast<const float*>(c.input), im2col, n_img, c.st));
     HMM_TRY(gemm_bf16(im2col, e->patch_w, nullptr, patch, n_img * e->n_patches, D, e->patch_k_pad, HMM_EPI_F32, -1, c.st));
     HMM_TRY(launch_assemble_tokens(patch, e->cls, e->pos, e->stem_g, e->stem_b, 1e-5f, e->pre_g, e->pre_b, 1e-6f,
                                    x, n_img, e->T, D, c.st));
@@ -297,9 +323,10 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
     const int D = e->D, T = e->T, R = p.R, n_img = p.n_img;
     const BlockW& w = e->blocks[i];
     HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
-    if (i + 1 < e->depth) {
+    const bool text = e->tower == HMM_TOWER_TEXT;     // the selected (EOS) row differs per sample: no cls-only shortcut
+    if (i + 1 < e->depth || text) {
         HMM_TRY(gemm_bf16(a, w.qkv_w, w.qkv_b, big, R, 3 * D, D, HMM_EPI_BIAS_BF16, -1, st));
-        HMM_TRY(attention_bf16(big, a, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st));
+        HMM_TRY(attention_bf16(big, a, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st, text));
         HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, -1, st));
         HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
         HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, -1, st));
@@ -327,6 +354,9 @@ static int chain_head(hmm_encoder* e, const Chain& c) {
     float* xc = reinterpret_cast<float*>(c.ws + p.off_xc);
     bf16_t* hl = reinterpret_cast<bf16_t*>(c.ws + p.off_hl);
     float* hv = reinterpret_cast<float*>(c.ws + p.off_hv);
+    if (e->tower == HMM_TOWER_TEXT)                    // SelectEOSAndProject: the row at the EOS position of each sample
+        HMM_TRY(launch_gather_selected_rows(c.ws + p.off_x, reinterpret_cast<const int32_t*>(c.ws + p.off_sel), e->T, xc,
+                                            p.n_img, e->D * 4, c.st));
     HMM_TRY(launch_layernorm_bf16(xc, (size_t)e->D, e->head_g, e->head_b, hl, p.n_img, e->D, 1e-6f, c.st));
     HMM_TRY(gemm_bf16(hl, e->head_w, nullptr, hv, p.n_img, HMM_FEATURE_DIM, e->D, HMM_EPI_F32, -1, c.st));
     HMM_TRY(launch_l2norm_rows(hv, c.out, c.batch, e->clips, e->log_scale, c.st));
@@ -336,7 +366,7 @@ static int chain_head(hmm_encoder* e, const Chain& c) {
 
 }  // namespace hmm
 
-extern "C" int hmm_encoder_forward(hmm_encoder* e, const float* input_dev, int batch, float* out_dev,
+extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int batch, float* out_dev,
                                    void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream) {
     HMM_REQUIRE(e && input_dev && out_dev && workspace_dev, HMM_E_INVALID, "encoder_forward: null argument");
     HMM_REQUIRE(batch >= 1, HMM_E_INVALID, "encoder_forward: batch=%d", batch);
@@ -350,7 +380,8 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const float* input_dev, int b
                 workspace_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(workspace_dev);
-    const size_t in_per_sample = e->tower == HMM_TOWER_VISION ? (size_t)3 * 224 * 224 : (size_t)3 * 128 * 204;
+    const size_t in_bytes_per_sample = e->tower == HMM_TOWER_VISION ? (size_t)3 * 224 * 224 * 4
+                                       : e->tower == HMM_TOWER_AUDIO ? (size_t)3 * 128 * 204 * 4 : (size_t)e->T * 8;
 
     Chain chains[2];
     int n_chains = 1;
@@ -365,7 +396,7 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const float* input_dev, int b
         }
         const WsPlan p0 = ws_plan(e, b0);
         chains[0] = Chain{input_dev, out_dev, ws, p0, st, b0};
-        chains[1] = Chain{input_dev + (size_t)b0 * in_per_sample, out_dev + (size_t)b0 * HMM_FEATURE_DIM,
+        chains[1] = Chain{static_cast<const char*>(input_dev) + (size_t)b0 * in_bytes_per_sample, out_dev + (size_t)b0 * HMM_FEATURE_DIM,
                           ws + p0.total, ws_plan(e, batch - b0), e->side_stream, batch - b0};
         n_chains = 2;
         HMM_HIP_CHECK(hipEventRecord(e->ev_fork, st));                       // fork

@@ -17,12 +17,17 @@ int launch_im2col_vision(const float* frames, bf16_t* out, int n_img, hipStream_
 int launch_im2col_audio(const float* mels, bf16_t* out, int n_clip, hipStream_t st);
 int launch_l2norm_rows(const float* v, float* out, int n_out, int clips, const float* log_scale, hipStream_t st);
 int launch_gather_rows(const void* src, size_t src_row_stride_bytes, void* dst, int n_rows, int row_bytes, hipStream_t st);
+int launch_embed_tokens(const int64_t* ids, const float* table, const float* pos, float* x, int n_rows, int T, int vocab,
+                        hipStream_t st);
+int launch_select_eos(const int64_t* ids, int32_t* sel, int batch, int T, hipStream_t st);
+int launch_gather_selected_rows(const void* src, const int32_t* sel, int T, void* dst, int n_rows, int row_bytes,
+                                hipStream_t st);
 int launch_cast_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t st);
 int launch_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);
 int launch_fold_conv3d(const float* w, bf16_t* dst, int D, hipStream_t st);
 
 int attention_bf16(const bf16_t* qkv, bf16_t* out, int batch, int tokens, int heads, int head_dim,
-                   const float* bias_k, const float* bias_v, hipStream_t st);
+                   const float* bias_k, const float* bias_v, hipStream_t st, bool causal = false);
 
 // last block: one query (the cls token) per (image, head); kv is [rows][2D] = [k | v]
 int attention_cls_bf16(const bf16_t* q_cls, const bf16_t* kv, bf16_t* out, int batch, int tokens, int heads,

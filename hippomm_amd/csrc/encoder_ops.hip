@@ -177,6 +177,55 @@ __global__ void gather_rows_kernel(const char* __restrict__ src, size_t src_row_
         *reinterpret_cast<const uint4*>(src + (size_t)r * src_row_stride_bytes + c * 16);
 }
 
+// text tower: x[b*T + t] = token_embedding[ids[b][t]] + pos_embed[t]    (D = 1024; one wave per token row)
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                           const float* __restrict__ pos, float* __restrict__ x,
+                                                           int n_rows, int T, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float* src = table + (size_t)id * 1024;
+    const float* pr = pos + (size_t)(row % T) * 1024;
+    float* dst = x + (size_t)row * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 a = *reinterpret_cast<const float4*>(src + 4 * (64 * j + lane));
+        const float4 p = *reinterpret_cast<const float4*>(pr + 4 * (64 * j + lane));
+        *reinterpret_cast<float4*>(dst + 4 * (64 * j + lane)) = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    }
+}
+
+// sel[b] = first position of the largest token id of sample b (the EOS token has the largest id)
+__global__ __launch_bounds__(64) void select_eos_kernel(const int64_t* __restrict__ ids, int32_t* __restrict__ sel, int T) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int64_t best = INT64_MIN;
+    int pos = 0x7FFFFFFF;
+    for (int t = lane; t < T; t += 64) {
+        const int64_t v = ids[(size_t)b * T + t];
+        if (v > best) { best = v; pos = t; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int64_t ob = __shfl_xor(best, off, 64);
+        const int op = __shfl_xor(pos, off, 64);
+        if (ob > best || (ob == best && op < pos)) { best = ob; pos = op; }
+    }
+    if (lane == 0) sel[b] = pos;
+}
+
+// dst[b] = src[(b*T + sel[b])]   rows of row_bytes (16-B pieces)
+__global__ void gather_selected_rows_kernel(const char* __restrict__ src, const int32_t* __restrict__ sel, int T,
+                                            char* __restrict__ dst, int n_rows, int row_bytes) {
+    const int per_row = row_bytes / 16;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_rows * per_row) return;
+    const int r = (int)(i / per_row), c = (int)(i % per_row);
+    *reinterpret_cast<uint4*>(dst + (size_t)r * row_bytes + c * 16) =
+        *reinterpret_cast<const uint4*>(src + ((size_t)r * T + sel[r]) * row_bytes + c * 16);
+}
+
 // ---- weight packing -------------------------------------------------------------------------
 __global__ void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -205,12 +254,13 @@ int g_ln_max_blocks = 0;   // tuning hook: > 0 caps the LayerNorm grid (persiste
 // ---- launchers ------------------------------------------------------------------------------
 int launch_layernorm_bf16(const float* x, size_t in_stride, const float* g, const float* b, bf16_t* y,
                           int rows, int D, float eps, hipStream_t st) {
-    HMM_REQUIRE(D == 768 || D == 1280, HMM_E_INVALID, "layernorm: D must be 768 or 1280, got %d", D);
+    HMM_REQUIRE(D == 768 || D == 1024 || D == 1280, HMM_E_INVALID, "layernorm: D must be 768, 1024 or 1280, got %d", D);
     if (rows <= 0) return HMM_OK;
     int blocks = (rows + 3) / 4;
     if (g_ln_max_blocks > 0 && blocks > g_ln_max_blocks) blocks = g_ln_max_blocks;
-    if (D == 768) layernorm_bf16_kernel<3><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps);
-    else          layernorm_bf16_kernel<5><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps);
+    if (D == 768)       layernorm_bf16_kernel<3><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps);
+    else if (D == 1024) layernorm_bf16_kernel<4><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps);
+    else                layernorm_bf16_kernel<5><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
@@ -248,6 +298,25 @@ int launch_gather_rows(const void* src, size_t src_row_stride_bytes, void* dst, 
     const int64_t n = (int64_t)n_rows * (row_bytes / 16);
     gather_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(static_cast<const char*>(src), src_row_stride_bytes,
                                                                    static_cast<char*>(dst), n_rows, row_bytes);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+int launch_embed_tokens(const int64_t* ids, const float* table, const float* pos, float* x, int n_rows, int T, int vocab,
+                        hipStream_t st) {
+    embed_tokens_kernel<<<(n_rows + 3) / 4, 256, 0, st>>>(ids, table, pos, x, n_rows, T, vocab);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+int launch_select_eos(const int64_t* ids, int32_t* sel, int batch, int T, hipStream_t st) {
+    select_eos_kernel<<<batch, 64, 0, st>>>(ids, sel, T);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+int launch_gather_selected_rows(const void* src, const int32_t* sel, int T, void* dst, int n_rows, int row_bytes,
+                                hipStream_t st) {
+    const int64_t n = (int64_t)n_rows * (row_bytes / 16);
+    gather_selected_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(static_cast<const char*>(src), sel, T,
+                                                                            static_cast<char*>(dst), n_rows, row_bytes);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }

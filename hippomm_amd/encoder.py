@@ -11,8 +11,9 @@ on the GPU and support ``.detach().cpu().numpy()`` (:480, :1186, :1335).
 Differences, all at construction time: the reference ignores ``model_path`` and downloads
 ``imagebind_huge(pretrained=True)`` (:31-35); here weights come from ``state_dict=`` (a mapping with
 the UPSTREAM key names) or from an ``imagebind_huge.pth`` found under ``model_path`` /
-``.checkpoints``; nothing is downloaded and a missing checkpoint raises.  The 'text' tower is not
-built (next).
+``.checkpoints``; nothing is downloaded and a missing checkpoint raises.  The 'text' tower
+takes CLIP-BPE token ids (B,77) int64: the BPE vocabulary file is not shipped, so strings need a
+``tokenizer=`` callable (str list -> (B,77) int64 tensor).
 """
 from __future__ import annotations
 
@@ -30,13 +31,16 @@ from . import _lib
 
 logger = logging.getLogger(__name__)
 
-TOWER_ID = {"vision": 0, "audio": 1}
-FULL_DEPTH = {"vision": 32, "audio": 12}
-INPUT_SHAPE = {"vision": (3, 224, 224), "audio": (3, 1, 128, 204)}
+TOWER_ID = {"vision": 0, "audio": 1, "text": 2}
+FULL_DEPTH = {"vision": 32, "audio": 12, "text": 24}
+INPUT_SHAPE = {"vision": (3, 224, 224), "audio": (3, 1, 128, 204), "text": (77,)}
+INPUT_DTYPE = {"vision": torch.float32, "audio": torch.float32, "text": torch.int64}
 _PREFIXES = {
     "vision": ("modality_preprocessors.vision.", "modality_trunks.vision.", "modality_heads.vision."),
     "audio": ("modality_preprocessors.audio.", "modality_trunks.audio.", "modality_heads.audio.",
               "modality_postprocessors.audio."),
+    "text": ("modality_preprocessors.text.", "modality_trunks.text.", "modality_heads.text.",
+             "modality_postprocessors.text."),
 }
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -69,6 +73,8 @@ class HipTower:
         used = 0
         for key, value in state_dict.items():
             if not key.startswith(_PREFIXES[self.name]):
+                continue
+            if key.endswith(".mask"):                   # text preprocessor's causal-mask buffer: built into the kernel
                 continue
             if ".blocks." in key:
                 blk = int(key.split(".blocks.")[1].split(".")[0])
@@ -116,7 +122,7 @@ class HipTower:
         if tuple(x.shape[1:]) != INPUT_SHAPE[self.name]:
             raise ValueError(f"{self.name} input must be (B,{','.join(map(str, INPUT_SHAPE[self.name]))}), "
                              f"got {tuple(x.shape)}")
-        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        x = x.to(device=self.device, dtype=INPUT_DTYPE[self.name]).contiguous()
         out = torch.empty(x.shape[0], 1024, dtype=torch.float32, device=self.device)
         for s in range(0, x.shape[0], max_batch):
             self.forward_into(x[s:s + max_batch], out[s:s + max_batch])
@@ -162,6 +168,29 @@ def synthetic_state_dict(towers: Iterable[str] = ("vision",), seed: int = 1234, 
         return torch.randn(*shape, generator=g, device=dev) * std
 
     for m in towers:
+        if m == "text":
+            D, mlp = 1024, 4096
+            pp, tr, hd = "modality_preprocessors.text.", "modality_trunks.text.", "modality_heads.text."
+            sd[pp + "token_embedding.weight"] = rn(49408, D)
+            sd[pp + "pos_embed"] = rn(1, 77, D)
+            for i in range((depth or {}).get(m, FULL_DEPTH[m])):
+                b = f"{tr}blocks.{i}."
+                for ln in ("norm_1", "norm_2"):
+                    sd[b + ln + ".weight"] = torch.ones(D, device=dev)
+                    sd[b + ln + ".bias"] = torch.zeros(D, device=dev)
+                sd[b + "attn.in_proj_weight"] = rn(3 * D, D)
+                sd[b + "attn.in_proj_bias"] = torch.zeros(3 * D, device=dev)
+                sd[b + "attn.out_proj.weight"] = rn(D, D)
+                sd[b + "attn.out_proj.bias"] = torch.zeros(D, device=dev)
+                sd[b + "mlp.fc1.weight"] = rn(mlp, D)
+                sd[b + "mlp.fc1.bias"] = torch.zeros(mlp, device=dev)
+                sd[b + "mlp.fc2.weight"] = rn(D, mlp)
+                sd[b + "mlp.fc2.bias"] = torch.zeros(D, device=dev)
+            sd[hd + "proj.0.weight"] = torch.ones(D, device=dev)
+            sd[hd + "proj.0.bias"] = torch.zeros(D, device=dev)
+            sd[hd + "proj.1.weight"] = rn(1024, D)
+            sd["modality_postprocessors.text.1.log_logit_scale"] = torch.full((1,), float(np.log(1 / 0.07)), device=dev)
+            continue
         D, mlp, T = (1280, 5120, 257) if m == "vision" else (768, 3072, 229)
         n_blk = (depth or {}).get(m, FULL_DEPTH[m])
         pp, tr, hd = (f"modality_preprocessors.{m}.", f"modality_trunks.{m}.", f"modality_heads.{m}.")
@@ -205,8 +234,10 @@ class ImageBind(nn.Module):
                  state_dict: Optional[Mapping[str, torch.Tensor]] = None,
                  towers: Iterable[str] = ("vision", "audio"),
                  depth: Optional[Dict[str, int]] = None,
-                 max_batch: Optional[Dict[str, int]] = None):
+                 max_batch: Optional[Dict[str, int]] = None,
+                 tokenizer=None):
         super().__init__()
+        self.tokenizer = tokenizer                  # str list -> (B,77) int64 (imagebind.data.load_and_transform_text)
         self.device = _lib.require_gpu()            # reference :26 falls back to cpu then calls .cuda() anyway (:33)
         self.model = self._load_model(model_path, state_dict, tuple(towers), depth or {},
                                       max_batch or {"vision": 256, "audio": 128})
@@ -258,8 +289,13 @@ class ImageBind(nn.Module):
                     [self._load_audio_file(p) for p in value]
                     raise NotImplementedError(
                         "waveform -> log-mel preprocessing is not built (SURVEY 8f-3); pass a (B,3,1,128,204) tensor")
+                elif modality == ModalityType.TEXT:
+                    if self.tokenizer is None:
+                        raise NotImplementedError("text needs a CLIP-BPE tokenizer (tokenizer= callable) or a "
+                                                  "(B,77) int64 token tensor; the vocabulary file is not shipped")
+                    transformed[modality] = self.tokenizer(list(value)).to(self.device)
                 else:
-                    raise NotImplementedError(f"modality {modality!r} is not built (SURVEY 8f-1)")
+                    raise NotImplementedError(f"modality {modality!r} is not built")
             except Exception as e:  # noqa: BLE001 - mirror of the reference's catch-all
                 logger.error(f"Error processing {modality}: {str(e)}")
                 continue

@@ -113,6 +113,8 @@ typedef struct hmm_encoder hmm_encoder;
 
 #define HMM_TOWER_VISION 0   /* (B,3,224,224) fp32 -> (B,1024) unit rows                   */
 #define HMM_TOWER_AUDIO  1   /* (B,3,1,128,204) fp32 -> (B,1024) = mean_3clips(20 * unit)  */
+#define HMM_TOWER_TEXT   2   /* (B,77) int64 CLIP-BPE token ids -> (B,1024) = exp(log_logit_scale) * unit
+                                (the query side of feature_search, hippocampal_memory.py:2173-2176) */
 
 /* depth <= 0 selects the imagebind_huge depth (32 vision / 12 audio); a smaller depth builds
  * the same tower with fewer blocks (used by CI-sized parity fixtures). */
@@ -129,9 +131,9 @@ int  hmm_encoder_load_param(hmm_encoder* enc, const char* upstream_key,
 int  hmm_encoder_missing_params(hmm_encoder* enc);
 
 size_t hmm_encoder_workspace_bytes(const hmm_encoder* enc, int batch);
-/* input_dev: vision (batch,3,224,224) fp32 | audio (batch,3,1,128,204) fp32
+/* input_dev: vision (batch,3,224,224) fp32 | audio (batch,3,1,128,204) fp32 | text (batch,77) int64
  * out_dev:   (batch,1024) fp32 */
-int  hmm_encoder_forward(hmm_encoder* enc, const float* input_dev, int batch, float* out_dev,
+int  hmm_encoder_forward(hmm_encoder* enc, const void* input_dev, int batch, float* out_dev,
                          void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
 /* FLOPs (2 x MAC) one forward of `batch` samples performs, for roofline accounting. */
 double hmm_encoder_flops(const hmm_encoder* enc, int batch);

@@ -35,6 +35,12 @@ audio   (B,3,1,128,204)  -> clips folded into the batch (3B,1,128,204)
       learned bias_k / bias_v appended as one extra key/value position
   head: LayerNorm(eps 1e-6) -> token 0 -> Linear(768, 1024, bias=False)
   post: L2 normalise, x exp(log_logit_scale)=20 (fixed), mean over the 3 clips
+
+text    (B,77) int64 BPE token ids (CLIP vocabulary 49408; the tokenizer file is not in this image)
+  token embedding + learned pos_embed (1,77,1024); causal attention mask
+  24 x block, 16 heads, MLP 4096, LayerNorm eps 1e-6
+  head: token at the EOS position (argmax of the ids) -> LayerNorm(eps 1e-6) -> Linear(1024,1024,bias=False)
+  post: L2 normalise, x exp(log_logit_scale) (init 1/0.07, learnable, clipped at 100)
 """
 from __future__ import annotations
 
@@ -74,6 +80,9 @@ class TowerSpec:
 
 VISION_HUGE = TowerSpec("vision", 1280, 32, 16, 5120, 256, 3 * 14 * 14, True, False, False, 1.0, 1)
 AUDIO_HUGE = TowerSpec("audio", 768, 12, 12, 3072, 228, 16 * 16, False, True, True, 20.0, 3)
+# text: n_patches + 1 = 77 token positions (no cls token; the EOS position is selected by the head)
+TEXT_HUGE = TowerSpec("text", 1024, 24, 16, 4096, 76, 0, False, False, False, 1.0 / 0.07, 1)
+TEXT_VOCAB = 49408
 
 
 def reduced(spec: TowerSpec, depth: int) -> TowerSpec:
@@ -115,9 +124,15 @@ def synthetic_state(spec: TowerSpec, seed: int = 1234, init: str = "survey",
             return base + spread * torch.randn(n, generator=g)
         return torch.full((n,), float(base))
 
-    st[pp + "cls_token"] = _tn(g, (1, 1, D), w_std)
-    st[pp + "pos_embedding_helper.pos_embed"] = _tn(g, (1, spec.tokens, D), w_std)
-    if m == "vision":
+    if m == "text":
+        st[pp + "token_embedding.weight"] = _tn(g, (TEXT_VOCAB, D), w_std)
+        st[pp + "pos_embed"] = _tn(g, (1, spec.tokens, D), 0.01)
+    else:
+        st[pp + "cls_token"] = _tn(g, (1, 1, D), w_std)
+        st[pp + "pos_embedding_helper.pos_embed"] = _tn(g, (1, spec.tokens, D), w_std)
+    if m == "text":
+        pass
+    elif m == "vision":
         st[pp + "rgbt_stem.proj.1.weight"] = _tn(g, (D, 3, 2, 14, 14), w_std)
     else:
         st[pp + "rgbt_stem.proj.weight"] = _tn(g, (D, 1, 16, 16), w_std)
@@ -143,6 +158,12 @@ def synthetic_state(spec: TowerSpec, seed: int = 1234, init: str = "survey",
         st[b + "mlp.fc1.bias"] = vec(spec.mlp_dim, 0.0, 0.02)
         st[b + "mlp.fc2.weight"] = _tn(g, (D, spec.mlp_dim), w_std)
         st[b + "mlp.fc2.bias"] = vec(D, 0.0, 0.02)
+    if m == "text":
+        st[hd + "proj.0.weight"] = vec(D, 1.0, 0.1)
+        st[hd + "proj.0.bias"] = vec(D, 0.0, 0.1)
+        st[hd + "proj.1.weight"] = _tn(g, (OUT_DIM, D), w_std)
+        st["modality_postprocessors.text.1.log_logit_scale"] = torch.tensor([math.log(spec.logit_scale)])
+        return st
     st[hd + "0.weight"] = vec(D, 1.0, 0.1)
     st[hd + "0.bias"] = vec(D, 0.0, 0.1)
     st[hd + "2.weight"] = _tn(g, (OUT_DIM, D), w_std)
@@ -151,7 +172,7 @@ def synthetic_state(spec: TowerSpec, seed: int = 1234, init: str = "survey",
     return st
 
 
-def _block(x_lbd, st, prefix, spec: TowerSpec):
+def _block(x_lbd, st, prefix, spec: TowerSpec, attn_mask=None):
     """One BlockWithMasking on (L,B,D) fp32, eval mode, no layer scale, no drop path."""
     D = spec.embed_dim
     y = F.layer_norm(x_lbd, (D,), st[prefix + "norm_1.weight"], st[prefix + "norm_1.bias"], 1e-6)
@@ -161,7 +182,7 @@ def _block(x_lbd, st, prefix, spec: TowerSpec):
         st.get(prefix + "attn.bias_k"), st.get(prefix + "attn.bias_v"),
         False, 0.0,
         st[prefix + "attn.out_proj.weight"], st[prefix + "attn.out_proj.bias"],
-        training=False, need_weights=False)
+        training=False, need_weights=False, attn_mask=attn_mask)
     x_lbd = x_lbd + attn
     y = F.layer_norm(x_lbd, (D,), st[prefix + "norm_2.weight"], st[prefix + "norm_2.bias"], 1e-6)
     y = F.linear(y, st[prefix + "mlp.fc1.weight"], st[prefix + "mlp.fc1.bias"])
@@ -230,6 +251,28 @@ def audio_forward(mels: torch.Tensor, st, spec: TowerSpec = AUDIO_HUGE) -> torch
 
 
 @torch.no_grad()
+def text_forward(tokens: torch.Tensor, st, spec: TowerSpec = TEXT_HUGE) -> torch.Tensor:
+    """(B,77) int64 BPE token ids -> (B,1024) = exp(log_logit_scale) x unit rows.  [upstream, recalled]:
+    TextPreprocessor (token embedding + learned positions, causal mask), 24 blocks, SelectEOSAndProject
+    (the EOS token has the largest id, so its position is tokens.argmax(-1)): LayerNorm(eps 1e-6) ->
+    Linear(1024,1024,bias=False); Normalize; LearnableLogitScaling(init 1/0.07, learnable, clipped at 100)."""
+    pp, tr, hd = "modality_preprocessors.text.", "modality_trunks.text.", "modality_heads.text."
+    D, L = spec.embed_dim, spec.tokens
+    x = F.embedding(tokens, st[pp + "token_embedding.weight"]) + st[pp + "pos_embed"]
+    mask = torch.full((L, L), float("-inf")).triu_(1)
+    x = x.transpose(0, 1)
+    for i in range(spec.depth):
+        x = _block(x, st, f"{tr}blocks.{i}.", spec, attn_mask=mask)
+    x = x.transpose(0, 1)
+    eos = tokens.argmax(dim=-1)
+    y = x[torch.arange(x.shape[0]), eos]
+    y = F.layer_norm(y, (D,), st[hd + "proj.0.weight"], st[hd + "proj.0.bias"], 1e-6)
+    y = F.linear(y, st[hd + "proj.1.weight"])
+    y = F.normalize(y, dim=-1)
+    return y * st["modality_postprocessors.text.1.log_logit_scale"].exp().clamp(max=100.0)
+
+
+@torch.no_grad()
 def forward(inputs: Dict[str, torch.Tensor], states: Dict[str, Dict[str, torch.Tensor]],
             specs: Dict[str, TowerSpec] | None = None) -> Dict[str, torch.Tensor]:
     """Mirror of ``ImageBindModel.forward`` for the two modalities on the hot path."""
@@ -240,6 +283,8 @@ def forward(inputs: Dict[str, torch.Tensor], states: Dict[str, Dict[str, torch.T
             out[key] = vision_forward(value, states[key], specs[key])
         elif key == "audio":
             out[key] = audio_forward(value, states[key], specs[key])
+        elif key == "text":
+            out[key] = text_forward(value, states[key], specs.get(key, TEXT_HUGE))
         else:
-            raise KeyError(f"oracle covers 'vision' and 'audio' only, got {key!r}")
+            raise KeyError(f"oracle covers 'vision', 'audio' and 'text' only, got {key!r}")
     return out

@@ -104,3 +104,36 @@ def test_missing_and_unexpected_weights_fail_loudly():
     wrong["modality_heads.vision.2.weight"] = torch.zeros(1000, 1280)
     with pytest.raises(_lib.HippoMMHipError, match="elements"):
         HipTower("vision", wrong, depth=1)
+
+
+@pytest.mark.parametrize("init", ["survey", "rich"])
+def test_text_tower_reduced_depth(init):
+    """CLIP-style text tower on token ids (causal mask, EOS-position select)."""
+    from hippomm_amd.encoder import HipTower
+    spec = ib.reduced(ib.TEXT_HUGE, 2)
+    st = ib.synthetic_state(spec, seed=77, init=init)
+    g = torch.Generator().manual_seed(0)
+    tok = torch.randint(1, 49000, (5, 77), generator=g)
+    for b, n in enumerate([1, 5, 20, 40, 76]):              # EOS (largest id) at various positions, zero padding after
+        tok[b, n] = 49407
+        tok[b, n + 1:] = 0
+    want = ib.text_forward(tok, st, spec)
+    got = HipTower("text", st, depth=2)(tok)
+    _check(got, want, scale=1.0 / 0.07, what=f"text depth2 {init}")
+
+
+def test_text_tower_full_depth_and_query_flow():
+    """24 blocks; the embedding is what feature_search takes as its query (hippocampal_memory.py:2173-2177)."""
+    from hippomm_amd.encoder import ImageBind
+    from hippomm_amd.vector_ops import top_k_cosine_similarity
+    st = ib.synthetic_state(ib.TEXT_HUGE, seed=5, init="survey")
+    tok = torch.zeros(2, 77, dtype=torch.int64)
+    tok[0, :4] = torch.tensor([49406, 320, 1125, 49407])
+    tok[1, :6] = torch.tensor([49406, 320, 2368, 539, 1237, 49407])
+    want = ib.text_forward(tok, st)
+    model = ImageBind(state_dict=st, towers=("text",))
+    got = model.forward({"text": tok.cuda()})["text"]
+    _check(got, want, scale=1.0 / 0.07, what="text full depth")
+    store = np.random.default_rng(0).standard_normal((50, 1024)).astype(np.float32)
+    idx, sims = top_k_cosine_similarity(got[0], store, 5)                   # torch CUDA query, as at :3130-3134
+    assert len(idx) == 5 and np.all(sims[:-1] >= sims[1:])

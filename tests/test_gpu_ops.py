@@ -149,7 +149,7 @@ def test_gemm_identity_asymmetric():
         assert torch.equal(y.cpu(), w.float().T)
 
 
-@pytest.mark.parametrize("rows,D", [(1, 768), (5, 1280), (1029, 1280), (700, 768)])
+@pytest.mark.parametrize("rows,D", [(1, 768), (5, 1280), (1029, 1280), (700, 768), (333, 1024)])
 def test_layernorm(rows, D):
     L, lib = _lib()
     g = torch.Generator().manual_seed(rows + D)
@@ -201,6 +201,28 @@ def test_attention(B, T, H, dh, bias, scale):
     tol = 2.0 ** -8 * want.abs() + 2.0 ** -8 * scale + 1e-4
     bad = (got - want).abs() > tol
     assert not bad.any(), f"{int(bad.sum())}/{bad.numel()} off; worst {float((got - want).abs().max()):.4g}"
+
+
+@pytest.mark.parametrize("B,T,H", [(3, 77, 16), (1, 33, 2), (2, 150, 4)])
+def test_attention_causal(B, T, H):
+    """Causal variant (text tower): query i sees keys 0..i."""
+    L, lib = _lib()
+    lib.hmm_dev_attention_causal_bf16.restype = C.c_int
+    lib.hmm_dev_attention_causal_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    dh, D = 64, H * 64
+    g = torch.Generator().manual_seed(T)
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 3.0).to(torch.bfloat16)
+    q, k, v = qkv.float().reshape(B, T, 3, H, dh).unbind(2)
+    q, k, v = (t.permute(0, 2, 1, 3) for t in (q, k, v))
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh) + torch.full((T, T), float("-inf")).triu_(1)
+    want = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * T, D)
+    out = torch.full((B * T, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    qd = qkv.cuda()
+    L.check(lib.hmm_dev_attention_causal_bf16(qd.data_ptr(), out.data_ptr(), B, T, H, dh, L.stream_ptr()), "attention")
+    got = out.float().cpu()
+    tol = 2.0 ** -8 * want.abs() + 2.0 ** -8 * 3.0 + 1e-4
+    bad = (got - want).abs() > tol
+    assert torch.isfinite(got).all() and not bad.any(), f"{int(bad.sum())}/{bad.numel()} off; worst {float((got - want).abs().max()):.4g}"
 
 
 def test_attention_one_hot_rows_pick_the_right_value():

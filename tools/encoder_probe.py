@@ -11,8 +11,11 @@ variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0
 sd = synthetic_state_dict((tower_name,))
 tower = HipTower(tower_name, sd)
 del sd
-shape = (B, 3, 224, 224) if tower_name == "vision" else (B, 3, 1, 128, 204)
-x = torch.randn(*shape, device="cuda")
+if tower_name == "text":
+    x = torch.randint(1, 49000, (B, 77), device="cuda"); x[:, 20] = 49407; x[:, 21:] = 0
+else:
+    shape = (B, 3, 224, 224) if tower_name == "vision" else (B, 3, 1, 128, 204)
+    x = torch.randn(*shape, device="cuda")
 out = torch.empty(B, 1024, device="cuda")
 import itertools
 streams = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [2]
