@@ -134,6 +134,30 @@ def scan_bench(do_cpu):
     return out
 
 
+def joint_bench():
+    """BASELINE configs[2]: vision + audio joint encode, 128 frame / 10 s-spectrogram pairs on one GPU."""
+    from hippomm_amd.encoder import HipTower, synthetic_state_dict
+    pairs = 128
+    sd = synthetic_state_dict(("vision", "audio"), seed=1234)
+    vis, aud = HipTower("vision", sd), HipTower("audio", sd)
+    del sd
+    frames = torch.randn(pairs, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    mels = torch.randn(pairs, 3, 1, 128, 204, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    ev, ea = torch.empty(pairs, 1024, device="cuda"), torch.empty(pairs, 1024, device="cuda")
+
+    def run():
+        vis.forward_into(frames, ev)
+        aud.forward_into(mels, ea)
+    ms = event_time_ms(run, 5, warmup=2)
+    flops = vis.flops(pairs) + aud.flops(pairs)
+    out = {"workload": "BASELINE cfg3: 128 frame + 10 s log-mel (3 clips) pairs, vision then audio tower",
+           "pairs_per_s": round(pairs / ms * 1e3, 1), "ms": round(ms, 3), "tflops": round(flops / ms / 1e9, 1),
+           "mfma_frac": round(flops / ms / 1e9 / PEAK_BF16_TFLOPS, 4)}
+    del vis, aud
+    torch.cuda.empty_cache()
+    return out
+
+
 def encoder_cpu_baseline():
     from oracle import imagebind_oracle as ib
     n = 8
@@ -234,6 +258,7 @@ def main():
             torch.cuda.empty_cache()
             if not args.no_scan:
                 line["scan"] = scan_bench(do_cpu=not args.no_cpu_baseline)
+                line["joint_vision_audio"] = joint_bench()
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = encoder_cpu_baseline()
         print(json.dumps(line), flush=True)

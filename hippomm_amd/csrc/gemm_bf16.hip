@@ -561,297 +561,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 }
 
 
-// Small-slab variant of the transposed epilogue for the persistent kernel, whose K-tile buffers stay busy
-// with the next tile's DMA: one 16-row MFMA block row at a time through a per-wave slab of 2304 B
-// (bf16: 16 rows x 144 B) / 4096 B (fp32: 16 rows x 256 B, XOR-swizzled 16-B chunks), same store shape
-// as gemm_epilogue_lds (whole 128-B lines per wave-instruction).
-constexpr int kSlabBf16 = 2304, kSlabF32 = 4096;
-
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_slab(f32x4 (&acc)[8][4], const float* __restrict__ bias,
-                                                   void* __restrict__ Cout, int M, int N, int m_wave, int n_wave,
-                                                   char* slab, int lane) {
-    const int fr = lane & 15, fq = lane >> 4;
-    float4 bv[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-        bv[ni] = bias ? *reinterpret_cast<const float4*>(bias + n_wave + ni * 16 + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
-
-    if constexpr (EPI == HMM_EPI_BIAS_BF16 || EPI == HMM_EPI_BIAS_GELU_BF16) {
-        constexpr int RS = 144;
-        bf16_t* C = static_cast<bf16_t*>(Cout);
-        const int rsub = lane >> 3, chunk = lane & 7;
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                f32x4 v = acc[mi][ni];
-                v[0] += bv[ni].x; v[1] += bv[ni].y; v[2] += bv[ni].z; v[3] += bv[ni].w;
-                if constexpr (EPI == HMM_EPI_BIAS_GELU_BF16) {
-                    v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-                }
-                bf16x4 o4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                *reinterpret_cast<bf16x4*>(slab + fr * RS + (ni * 16 + 4 * fq) * 2) = o4;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            uint4 v2[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) v2[j] = *reinterpret_cast<const uint4*>(slab + (j * 8 + rsub) * RS + chunk * 16);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int m = m_wave + mi * 16 + j * 8 + rsub;
-                if (m < M) *reinterpret_cast<uint4*>(C + (size_t)m * N + n_wave + chunk * 8) = v2[j];
-            }
-        }
-    } else {
-        float* C = static_cast<float*>(Cout);
-        const int rsub = lane >> 4, chunk = lane & 15;
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            float4 xin[4];
-            if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = m_wave + mi * 16 + j * 4 + rsub;
-                    xin[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (m < M) xin[j] = *reinterpret_cast<const float4*>(C + (size_t)m * N + n_wave + chunk * 4);
-                }
-            }
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const f32x4 a = acc[mi][ni];
-                *reinterpret_cast<float4*>(slab + fr * 256 + (((ni * 4 + fq) ^ fr) & 15) * 16) =
-                    make_float4(a[0] + bv[ni].x, a[1] + bv[ni].y, a[2] + bv[ni].z, a[3] + bv[ni].w);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            float4 v4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = j * 4 + rsub;
-                v4[j] = *reinterpret_cast<const float4*>(slab + row * 256 + ((chunk ^ row) & 15) * 16);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = m_wave + mi * 16 + j * 4 + rsub;
-                float4 v = v4[j];
-                if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
-                    v.x += xin[j].x; v.y += xin[j].y; v.z += xin[j].z; v.w += xin[j].w;
-                }
-                if (m < M) *reinterpret_cast<float4*>(C + (size_t)m * N + n_wave + chunk * 4) = v;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Persistent ping-pong variant.  Same 8-phase K-tile body as gemm_bf16_pp_kernel, but one workgroup
-// per CU walks a sequence of output tiles and the LDS-DMA stream never stops at a tile boundary: in
-// the last two K-tiles of tile i the phases stage K-tiles 0 and 1 of tile i+1 (the staging pointers
-// are switched to the next tile, pre-biased by -K so that the same `src + kt*64` expression lands on
-// its K-tile kt-KT).  The next tile therefore starts with its prologue already in LDS, and the
-// epilogue's global stores of tile i drain underneath the main loop of tile i+1.
-// ------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(
-    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    void* __restrict__ Cout, int M, int N, int K, int tiles_n, int n_tiles) {
-    constexpr int HALF = 16384, TILE = 4 * HALF;
-    constexpr int H_ALO = 0, H_AHI = HALF, H_BLO = 2 * HALF, H_BHI = 3 * HALF;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    // linear tile id -> (m0, n0), XCD-aware (ids with equal id%8 walk neighbouring tiles)
-    const int q8 = n_tiles >> 3, r8 = n_tiles & 7;
-    auto tile_origin = [&](int id, int& m0, int& n0) {
-        const int xcd = id & 7;
-        const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
-        m0 = (swz / tiles_n) * 256;
-        n0 = (swz % tiles_n) * 256;
-    };
-
-    // staging sources as 32-bit element offsets from A / W (uniform bases stay in SGPRs)
-    int src_alo[2], src_ahi[2], src_blo[2], src_bhi[2];
-    // staging sources of the tile at (m0,n0), biased by `kbias` elements along K
-    auto set_a_lo = [&](int m0, int kbias) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int lr = (wave + 8 * j) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((lr >> 1) & 7);
-            int g0 = m0 + (lr & 63) + (lr >> 6) * 128;
-            g0 = g0 < M ? g0 : M - 1;
-            src_alo[j] = g0 * K + c * 8 + kbias;
-        }
-    };
-    auto set_a_hi = [&](int m0, int kbias) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int lr = (wave + 8 * j) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((lr >> 1) & 7);
-            int g1 = m0 + (lr & 63) + (lr >> 6) * 128 + 64;
-            g1 = g1 < M ? g1 : M - 1;
-            src_ahi[j] = g1 * K + c * 8 + kbias;
-        }
-    };
-    auto set_b = [&](int n0, int kbias) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int lr = (wave + 8 * j) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((lr >> 1) & 7);
-            const int bcol = (lr >> 5) * 64 + (lr & 31);
-            src_blo[j] = (n0 + bcol) * K + c * 8 + kbias;
-            src_bhi[j] = (n0 + bcol + 32) * K + c * 8 + kbias;
-        }
-    };
-#define HMM_STAGE2(base, src, kt, buf, half)                                                                \
-    do {                                                                                                    \
-        __builtin_amdgcn_global_load_lds(HMM_GLB_PTR((base) + (ptrdiff_t)(src[0] + (kt) * 64)),             \
-                                         HMM_LDS_PTR(smem + (buf) * TILE + (half) + wave * 1024), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds(HMM_GLB_PTR((base) + (ptrdiff_t)(src[1] + (kt) * 64)),             \
-                                         HMM_LDS_PTR(smem + (buf) * TILE + (half) + (wave + 8) * 1024), 16, 0, 0); \
-    } while (0)
-
-    const int fsw = (lane & 15) >> 1;
-    const int ck0 = ((lane >> 4) ^ fsw) * 16, ck1 = ((4 + (lane >> 4)) ^ fsw) * 16;
-    const char* a_rd = smem + (wm * 64 + (lane & 15)) * 128;
-    const char* b_rd = smem + (wn * 32 + (lane & 15)) * 128;
-
-    f32x4 acc[8][4];
-    bf16x8 af[4][2], blo[2][2], bhi[2][2];
-
-#define HMM_READ_A(buf, half)                                                                        \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                               \
-        af[mi][0] = *reinterpret_cast<const bf16x8*>(a_rd + (buf) * TILE + (half) + mi * 2048 + ck0); \
-        af[mi][1] = *reinterpret_cast<const bf16x8*>(a_rd + (buf) * TILE + (half) + mi * 2048 + ck1); \
-    }
-#define HMM_READ_B(dst, buf, half)                                                                    \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                \
-        dst[ni][0] = *reinterpret_cast<const bf16x8*>(b_rd + (buf) * TILE + (half) + ni * 2048 + ck0); \
-        dst[ni][1] = *reinterpret_cast<const bf16x8*>(b_rd + (buf) * TILE + (half) + ni * 2048 + ck1); \
-    }
-#define HMM_MFMA_QUAD(mo, no, bsrc)                                                                   \
-    __builtin_amdgcn_s_setprio(1);                                                                    \
-    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                  \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
-        acc[(mo) + mi][(no) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[ni][kh], af[mi][kh], \
-                                                                            acc[(mo) + mi][(no) + ni], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);
-
-    const int KT = K >> 6;                                    // even, >= 2 (checked by the launcher)
-    int tile = blockIdx.x;
-    int m0, n0;
-    tile_origin(tile, m0, n0);
-    set_a_lo(m0, 0); set_a_hi(m0, 0); set_b(n0, 0);
-    // prologue of the first tile: K-tile 0 complete, K-tile 1 minus A_hi
-    HMM_STAGE2(A, src_alo, 0, 0, H_ALO); HMM_STAGE2(W, src_blo, 0, 0, H_BLO);
-    HMM_STAGE2(W, src_bhi, 0, 0, H_BHI); HMM_STAGE2(A, src_ahi, 0, 0, H_AHI);
-    HMM_STAGE2(A, src_alo, 1, 1, H_ALO); HMM_STAGE2(W, src_blo, 1, 1, H_BLO); HMM_STAGE2(W, src_bhi, 1, 1, H_BHI);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    HMM_BAR();
-    if (wm == 1) { HMM_BAR(); }                               // waves 4-7 run one barrier behind
-
-    // `more`: staging continues past this tile's last K-tile (into the next tile)
-#define HMM_KTILE(t, buf)                                                                 \
-    {                                                                                     \
-        /* P1: quadrant (lo,lo) */                                                        \
-        HMM_READ_A(buf, H_ALO) HMM_READ_B(blo, buf, H_BLO)                                \
-        if ((t) + 1 < KT || more) HMM_STAGE2(A, src_ahi, (t) + 1, (buf) ^ 1, H_AHI);          \
-        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(0, 0, blo) HMM_BAR()                         \
-        /* P2: (lo,hi) */                                                                 \
-        HMM_READ_B(bhi, buf, H_BHI)                                                       \
-        if ((t) + 2 < KT || more) HMM_STAGE2(A, src_alo, (t) + 2, buf, H_ALO);                \
-        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(0, 2, bhi) HMM_BAR()                         \
-        /* P3: (hi,hi) */                                                                 \
-        HMM_READ_A(buf, H_AHI)                                                            \
-        if ((t) + 2 < KT || more) HMM_STAGE2(W, src_blo, (t) + 2, buf, H_BLO);                \
-        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(4, 2, bhi) HMM_BAR()                         \
-        /* P4: (hi,lo) */                                                                 \
-        if ((t) + 2 < KT || more) {                                                       \
-            HMM_STAGE2(W, src_bhi, (t) + 2, buf, H_BHI);                                      \
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                              \
-        } else {                                                                          \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              \
-        }                                                                                 \
-        HMM_BAR() HMM_MFMA_QUAD(4, 0, blo) HMM_BAR()                                      \
-    }
-
-    while (true) {
-        const int next = tile + (int)gridDim.x;
-        const bool more = next < n_tiles;                     // block-uniform
-        int m0n = 0, n0n = 0;
-        if (more) tile_origin(next, m0n, n0n);
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        for (int t = 0; t < KT; t += 2) {
-            if (more && t == KT - 2) {                        // from here A_lo/B_lo/B_hi stage the next tile
-                set_a_lo(m0n, -K);
-                set_b(n0n, -K);
-            }
-            HMM_KTILE(t, 0)
-            if (more && t == KT - 2) set_a_hi(m0n, -K);       // (KT-1).A_hi was the last use of this tile's A_hi
-            HMM_KTILE(t + 1, 1)
-        }
-
-        {
-            constexpr int SLAB = (EPI == HMM_EPI_BIAS_BF16 || EPI == HMM_EPI_BIAS_GELU_BF16) ? kSlabBf16 : kSlabF32;
-            gemm_epilogue_slab<EPI>(acc, bias, Cout, M, N, m0 + wm * 128, n0 + wn * 64, smem + 2 * TILE + wave * SLAB, lane);
-        }
-        if (!more) break;
-        tile = next; m0 = m0n; n0 = n0n;
-        // re-base the pointers so that K-tile indices restart at 0 for the new tile
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { src_alo[j] += K; src_ahi[j] += K; src_blo[j] += K; src_bhi[j] += K; }
-    }
-    if (wm == 0) { HMM_BAR(); }                               // re-align the two wave groups
-#undef HMM_KTILE
-#undef HMM_STAGE2
-#undef HMM_READ_A
-#undef HMM_READ_B
-#undef HMM_MFMA_QUAD
-}
-
-template <int EPI>
-static int launch_gemm_pp2(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, hipStream_t st) {
-    constexpr int LDS = 2 * 4 * 16384 + 8 * ((EPI == HMM_EPI_BIAS_BF16 || EPI == HMM_EPI_BIAS_GELU_BF16) ? kSlabBf16 : kSlabF32);
-    auto kern = gemm_bf16_pp2_kernel<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
-    const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
-    const int n_tiles = tiles_m * tiles_n;
-    const int grid = n_tiles < kNumCU ? n_tiles : kNumCU;
-    kern<<<grid, 512, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n, n_tiles);
-    HMM_LAUNCH_CHECK();
-    return HMM_OK;
-}
-
-static int launch_gemm_pp2_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                               int epi, hipStream_t st) {
-    switch (epi) {
-        case HMM_EPI_BIAS_BF16:      return launch_gemm_pp2<HMM_EPI_BIAS_BF16>(A, W, bias, C, M, N, K, st);
-        case HMM_EPI_BIAS_GELU_BF16: return launch_gemm_pp2<HMM_EPI_BIAS_GELU_BF16>(A, W, bias, C, M, N, K, st);
-        case HMM_EPI_BIAS_RESID_F32: return launch_gemm_pp2<HMM_EPI_BIAS_RESID_F32>(A, W, bias, C, M, N, K, st);
-        case HMM_EPI_F32:            return launch_gemm_pp2<HMM_EPI_F32>(A, W, bias, C, M, N, K, st);
-    }
-    set_error("gemm: unknown epilogue %d", epi);
-    return HMM_E_INVALID;
-}
-
 template <int EPI, int F = 0>
 static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, hipStream_t st) {
     constexpr int LDS = (8 * kEpiSlab > 2 * 4 * 16384 ? 8 * kEpiSlab : 2 * 4 * 16384) + 8 * 256;   // + residual-prefetch sink
@@ -946,11 +655,6 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
             case 512: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 512>(A, W, bias, C, M, N, K, st);
             case 56: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 56>(A, W, bias, C, M, N, K, st);
         }
-    }
-    if (variant == 5) {
-        if (N % 256 != 0 || K % 128 != 0) return gemm_bf16(A, W, bias, C, M, N, K, epi, 2, st);
-        if ((size_t)M * K >= (1ull << 31) || (size_t)N * K >= (1ull << 31)) return gemm_bf16(A, W, bias, C, M, N, K, epi, 3, st);
-        return launch_gemm_pp2_epi(A, W, bias, C, M, N, K, epi, st);
     }
     if (variant == 4) {
         // Tile quantisation: with 256 CUs and one 256x256 tile per CU, T tiles take ceil(T/256) rounds.
