@@ -40,11 +40,11 @@ struct AttnCfg {
 };
 
 constexpr int kAttnWaves = 8;
-int g_attn_reverse = 1;   // tuning hook: walk images last-to-first (Infinity-Cache locality after the QKV GEMM)
+int g_attn_reverse = 9;   // tuning hook: 1 = walk images last-to-first, 8 = XCD-aware block order (see the kernel)
 
 template <int DH, int NKT>
 __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
-    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T, int Lk, int H,
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n_img, int T, int Lk, int H,
     const float* __restrict__ bias_k, const float* __restrict__ bias_v, float scale_log2e, int reverse) {
     using C = AttnCfg<DH, NKT>;
     constexpr int NT = kAttnWaves * 64;
@@ -59,8 +59,19 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // walk the images backwards: the producer (QKV GEMM) wrote the last images last, so they are the
     // ones still resident in the 256-MiB Infinity Cache when this kernel starts
-    const int b_lin = blockIdx.x / H;
-    const int b = (reverse & 1) ? (int)(gridDim.x / H) - 1 - b_lin : b_lin, h = blockIdx.x % H;
+    // XCD x = blockIdx % 8 takes the images x, x+8, ...: the 16 heads of an image then run on one XCD at about the same
+    // time, and a head's 160-B slice of a qkv row shares its 128-B lines with its neighbours' in that XCD's L2
+    int b_lin, h;
+    if (reverse & 8) {
+        const int n = blockIdx.x >> 3;
+        b_lin = (blockIdx.x & 7) + 8 * (n / H);
+        h = n % H;
+        if (b_lin >= n_img) return;
+    } else {
+        b_lin = blockIdx.x / H;
+        h = blockIdx.x % H;
+    }
+    const int b = (reverse & 1) ? n_img - 1 - b_lin : b_lin;
     const bool abl_nocompute = reverse & 2, abl_noload = reverse & 4;   // timing ablations (wrong results)
     const bool causal = reverse & 256;                                  // text tower: key j visible to query i iff j <= i
     const int D = H * DH;
@@ -243,22 +254,27 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
             }
         }
 
+        // A lane holds 4 consecutive d (8 B) per accumulator group and its partner lane^32 the next 4;
+        // v_permlane32_swap pairs two groups so that every lane stores 16 B (half the store instructions, 32-B pieces).
         const float l = l_run + __shfl_xor(l_run, 32, 64);
-        if (qrow < T) {
-            const float inv_l = 1.0f / l;
-            bf16_t* op = out + ((size_t)b * T + qrow) * D + h * DH;
+        const float inv_l = 1.0f / l;
+        bf16_t* op = out + ((size_t)b * T + (qrow < T ? qrow : T - 1)) * D + h * DH + 8 * hh;
 #pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt)
+        for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int d0 = dt * 32 + 8 * gq + 4 * hh;
-                    if (d0 < DH) {
-                        bf16x4 o4 = {(bf16_t)(o[dt][4 * gq + 0] * inv_l), (bf16_t)(o[dt][4 * gq + 1] * inv_l),
-                                     (bf16_t)(o[dt][4 * gq + 2] * inv_l), (bf16_t)(o[dt][4 * gq + 3] * inv_l)};
-                        *reinterpret_cast<bf16x4*>(op + d0) = o4;
-                    }
+            for (int m = 0; m < 2; ++m) {
+                if (dt * 32 + 16 * m < DH) {                          // compile-time: 5 (dh 80) / 4 (dh 64) stores
+                    const int ra = 8 * m, rb = 8 * m + 4;             // accumulator groups gq = 2m and 2m+1
+                    bf16x4 a4 = {(bf16_t)(o[dt][ra + 0] * inv_l), (bf16_t)(o[dt][ra + 1] * inv_l),
+                                 (bf16_t)(o[dt][ra + 2] * inv_l), (bf16_t)(o[dt][ra + 3] * inv_l)};
+                    bf16x4 b4 = {(bf16_t)(o[dt][rb + 0] * inv_l), (bf16_t)(o[dt][rb + 1] * inv_l),
+                                 (bf16_t)(o[dt][rb + 2] * inv_l), (bf16_t)(o[dt][rb + 3] * inv_l)};
+                    const uint2 pa = __builtin_bit_cast(uint2, a4), pb = __builtin_bit_cast(uint2, b4);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
+                    if (qrow < T) *reinterpret_cast<uint4*>(op + dt * 32 + 16 * m) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                 }
-        }
+            }
     }
 
     if (coop && !abl_nocompute) {
@@ -353,8 +369,9 @@ static int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int T, in
         attr_set = true;
     }
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
-    kern<<<batch * H, kAttnWaves * 64, C::LDS, st>>>(qkv, out, T, Lk, H, bias_k, bias_v, scale_log2e,
-                                                     g_attn_reverse | (causal ? 256 : 0));
+    const int grid = (g_attn_reverse & 8) ? 8 * ((batch + 7) / 8) * H : batch * H;
+    kern<<<grid, kAttnWaves * 64, C::LDS, st>>>(qkv, out, batch, T, Lk, H, bias_k, bias_v, scale_log2e,
+                                                g_attn_reverse | (causal ? 256 : 0));
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
