@@ -269,8 +269,8 @@ class ImageBind(nn.Module):
 
         vision: list of image paths / PIL images (opened by path via ``.filename``, :83-86): decoded on the host,
         then resized (Pillow-identical bicubic, short side 224), centre-cropped and CLIP-normalised on the GPU
-        (hippomm_amd/preprocess.py); or an already preprocessed (B,3,224,224) tensor.  audio: a preprocessed (B,3,1,128,204) log-mel tensor; wav paths need
-        the kaldi filterbank front end (not built) and are rejected."""
+        (hippomm_amd/preprocess.py); or an already preprocessed (B,3,224,224) tensor.  audio: 16 kHz wav paths (three
+        2-second clips -> kaldi log-mel filterbank on the GPU, hmm_audio_fbank) or a preprocessed (B,3,1,128,204) tensor."""
         transformed = {}
         for modality in modalities:
             if modality not in inputs:
@@ -286,9 +286,9 @@ class ImageBind(nn.Module):
                 elif modality == ModalityType.AUDIO:
                     if not all(isinstance(x, str) for x in value):
                         raise ValueError("Audio inputs must be file paths. Direct tensor/array inputs are not supported.")
-                    [self._load_audio_file(p) for p in value]
-                    raise NotImplementedError(
-                        "waveform -> log-mel preprocessing is not built (SURVEY 8f-3); pass a (B,3,1,128,204) tensor")
+                    paths = [self._load_audio_file(p) for p in value]
+                    from .preprocess import load_and_transform_audio_data_device       # wav read on host, fbank on GPU
+                    transformed[modality] = load_and_transform_audio_data_device(paths, self.device)
                 elif modality == ModalityType.TEXT:
                     if self.tokenizer is None:
                         raise NotImplementedError("text needs a CLIP-BPE tokenizer (tokenizer= callable) or a "

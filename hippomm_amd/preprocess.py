@@ -121,3 +121,122 @@ def load_and_transform_vision_data_device(image_paths: Sequence[str], device=Non
         batch = torch.from_numpy(np.stack([decoded[i] for i in idxs])).to(dev)
         out[torch.tensor(idxs, device=dev)] = preprocess_frames_device(batch)
     return out
+
+
+# =====================================================================================================
+# Audio (audio half): wav samples -> (B,3,1,128,204) normalised log-mel clips on the GPU.
+# Mirrors imagebind.data.load_and_transform_audio_data [upstream, recalled] (called at
+# hippomm/models/foundation_models.py:106-109): three 2-second clips spread evenly over the file
+# (pytorchvideo ConstantClipsPerVideoSampler), per clip `waveform -= waveform.mean()`, kaldi fbank (128 mel bins,
+# 25 ms / 10 ms, Hann, 16 kHz), zero-pad to 204 frames, Normalize(-4.268, 9.138).  The host reads the wav and slices
+# the clips; hmm_audio_fbank does everything else.
+# =====================================================================================================
+AUDIO_SAMPLE_RATE = 16000
+AUDIO_CLIP_DURATION = 2
+AUDIO_CLIPS_PER_VIDEO = 3
+AUDIO_MEAN, AUDIO_STD = -4.268, 9.138
+AUDIO_MEL_BINS, AUDIO_TARGET_LENGTH = 128, 204
+
+
+def audio_clip_bounds(n_samples: int, sample_rate: int = AUDIO_SAMPLE_RATE) -> List[Tuple[int, int]]:
+    """Sample ranges of the 3 clips: starts spread evenly over [0, duration - 2 s] in exact rational arithmetic,
+    then `int(t * sample_rate)` as upstream slices the waveform."""
+    from fractions import Fraction
+    duration = n_samples / sample_rate
+    max_start = Fraction(max(duration - AUDIO_CLIP_DURATION, 0))
+    step = Fraction(max_start, max(AUDIO_CLIPS_PER_VIDEO - 1, 1))
+    out = []
+    for i in range(AUDIO_CLIPS_PER_VIDEO):
+        start, end = step * i, step * i + AUDIO_CLIP_DURATION
+        out.append((int(start * sample_rate), min(int(end * sample_rate), n_samples)))
+    return out
+
+
+def read_wav(path: str) -> Tuple[np.ndarray, int]:
+    """-> (samples float32 in [-1, 1] shaped (channels, n), sample_rate).  The reference writes its segment files with
+    scipy.io.wavfile (hippocampal_memory.py:1219, float32) or ffmpeg pcm_s16le (:1386-1394); torchaudio.load
+    normalises integer PCM to [-1, 1), which is reproduced here."""
+    from scipy.io import wavfile
+    rate, data = wavfile.read(path)
+    if data.ndim == 1:
+        data = data[:, None]
+    if data.dtype == np.int16:
+        x = data.astype(np.float32) / 32768.0
+    elif data.dtype == np.int32:
+        x = data.astype(np.float32) / 2147483648.0
+    elif data.dtype == np.uint8:
+        x = (data.astype(np.float32) - 128.0) / 128.0
+    else:
+        x = data.astype(np.float32)
+    return np.ascontiguousarray(x.T), int(rate)
+
+
+@lru_cache(maxsize=4)
+def _fbank_tables(device_str: str) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Hann window (400) and kaldi mel banks (128, 257) in the float32 torch CPU arithmetic torchaudio uses
+    (torchaudio.compliance.kaldi.get_mel_banks / _feature_window_function [upstream, recalled]), uploaded once."""
+    window = torch.hann_window(400, periodic=False)
+    num_bins, n_fft_bins, fft_bin_width = AUDIO_MEL_BINS, 256, AUDIO_SAMPLE_RATE / 512
+    mel_low = 1127.0 * math.log(1.0 + 20.0 / 700.0)
+    mel_high = 1127.0 * math.log(1.0 + 0.5 * AUDIO_SAMPLE_RATE / 700.0)
+    delta = (mel_high - mel_low) / (num_bins + 1)
+    b = torch.arange(num_bins).unsqueeze(1)
+    left, center, right = mel_low + b * delta, mel_low + (b + 1.0) * delta, mel_low + (b + 2.0) * delta
+    mel = (1127.0 * (1.0 + (fft_bin_width * torch.arange(n_fft_bins)) / 700.0).log()).unsqueeze(0)
+    banks = torch.max(torch.zeros(1), torch.min((mel - left) / (center - left), (right - mel) / (right - center)))
+    banks = torch.nn.functional.pad(banks, (0, 1)).contiguous()
+    return window.to(device_str), banks.to(device_str)
+
+
+def melspec_clips_device(clips: torch.Tensor, mean: float = AUDIO_MEAN, std: float = AUDIO_STD) -> torch.Tensor:
+    """clips: (n_clips, clip_len) fp32 CUDA, mono 16 kHz -> (n_clips, 128, 204) fp32 CUDA (asynchronous)."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    if clips.dim() != 2 or clips.dtype != torch.float32 or not clips.is_cuda:
+        raise ValueError("clips must be a 2-D float32 CUDA tensor (n_clips, clip_len)")
+    clips = clips.contiguous()
+    n, clip_len = clips.shape
+    out = torch.empty(n, AUDIO_MEL_BINS, AUDIO_TARGET_LENGTH, dtype=torch.float32, device=clips.device)
+    ws = torch.empty(lib.hmm_audio_fbank_workspace_bytes(n), dtype=torch.uint8, device=clips.device)
+    window, banks = _fbank_tables(str(clips.device))
+    _lib.check(lib.hmm_audio_fbank(clips.data_ptr(), n, clip_len, clip_len, window.data_ptr(), banks.data_ptr(),
+                                   float(mean), float(std), out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+               "hmm_audio_fbank")
+    return out
+
+
+def transform_waveforms_device(waveforms: Sequence, device, sample_rate: int = AUDIO_SAMPLE_RATE) -> torch.Tensor:
+    """waveforms: per file a (channels, n) or (n,) float array / tensor at 16 kHz -> (B,3,1,128,204) fp32 on `device`.
+    Channel 0 is analysed (kaldi.fbank's default channel).  Upstream's `waveform -= waveform.mean()` runs over all
+    channels, but any constant offset is removed again per frame (remove_dc_offset), so for multi-channel input the
+    result differs from the mono rule only in rounding; the reference always writes mono (:1204-1207, ffmpeg -ac 1)."""
+    if sample_rate != AUDIO_SAMPLE_RATE:
+        raise ValueError(f"audio must be sampled at {AUDIO_SAMPLE_RATE} Hz (got {sample_rate}); the reference extracts "
+                         "its audio with ffmpeg -ar 16000, resampling is not built")
+    groups = {}                                      # clip length -> [(file index, clip index, samples)]
+    for fi, w in enumerate(waveforms):
+        w = torch.as_tensor(np.asarray(w) if not isinstance(w, torch.Tensor) else w, dtype=torch.float32)
+        if w.dim() == 1:
+            w = w[None]
+        for ci, (s, e) in enumerate(audio_clip_bounds(w.shape[1], sample_rate)):
+            groups.setdefault(e - s, []).append((fi, ci, w[0, s:e]))
+    out = torch.empty(len(waveforms), AUDIO_CLIPS_PER_VIDEO, 1, AUDIO_MEL_BINS, AUDIO_TARGET_LENGTH,
+                      dtype=torch.float32, device=device)
+    for clip_len, items in groups.items():
+        batch = torch.stack([c for _, _, c in items]).to(device)
+        mel = melspec_clips_device(batch)
+        fidx = torch.tensor([f for f, _, _ in items], device=device)
+        cidx = torch.tensor([c for _, c, _ in items], device=device)
+        out[fidx, cidx, 0] = mel
+    return out
+
+
+def load_and_transform_audio_data_device(audio_paths: Sequence[str], device) -> torch.Tensor:
+    """Drop-in for imagebind.data.load_and_transform_audio_data(audio_paths, device) on 16 kHz wav files."""
+    waves = []
+    for p in audio_paths:
+        x, rate = read_wav(p)
+        if rate != AUDIO_SAMPLE_RATE:
+            raise ValueError(f"{p}: sample rate {rate} Hz, expected {AUDIO_SAMPLE_RATE} (resampling is not built)")
+        waves.append(x)
+    return transform_waveforms_device(waves, device)

@@ -155,6 +155,25 @@ int    hmm_preprocess_vision_u8(const uint8_t* frames_dev, int batch, int in_h, 
                                 void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Device-side audio front end.  Replaces waveform2melspec + Normalize inside
+ * imagebind.data.load_and_transform_audio_data [upstream, recalled] as called at
+ * hippomm/models/foundation_models.py:106-109: per clip, `waveform -= waveform.mean()`, then
+ * torchaudio.compliance.kaldi.fbank(htk_compat=True, sample_frequency=16000, use_energy=False, window_type="hanning",
+ * num_mel_bins=128, dither=0.0, frame_length=25, frame_shift=10), transposed to (128, frames), zero-padded / cut to
+ * 204 frames, then (x - mean) / std.  clips_dev: n_clips mono fp32 clips at 16 kHz, clip c at clips_dev + c*clip_stride,
+ * clip_len samples each (2 s = 32000 in the reference).  out_dev: (n_clips, 128, 204) fp32, i.e. the (B,3,1,128,204)
+ * tensor the audio tower takes when n_clips = 3*B.  Clip selection (3 clips spread over the segment) is host logic.
+ * window_dev (400 floats: torch.hann_window(400, periodic=False)) and mel_banks_dev (128 x 257 floats: kaldi
+ * get_mel_banks(128, 512, 16000, 20, 0) plus one zero column) may be null, in which case the library generates them on
+ * the device from the same formulas; pass tables computed on the host to reproduce torchaudio's weights to the bit.
+ * ---------------------------------------------------------------------------------------- */
+size_t hmm_audio_fbank_workspace_bytes(int n_clips);
+int    hmm_audio_fbank(const float* clips_dev, int n_clips, int clip_len, int64_t clip_stride,
+                       const float* window_dev, const float* mel_banks_dev,
+                       float norm_mean, float norm_std, float* out_dev,
+                       void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Building blocks of the encoder, exported so that each kernel is parity-tested on its own
  * against a torch fp32 reference of the same op (tests/test_gpu_ops.py) and timed on its own
  * (bench.py roofline).  bf16 tensors are raw uint16 bit patterns in device memory.

@@ -1,0 +1,227 @@
+"""Audio front end: oracle known answers on the CPU, HIP parity on the GPU.
+
+The oracle is unpinned by the reference (torchaudio / ImageBind absent, see its header); the CPU tests below pin it to
+closed-form properties of the published kaldi-fbank definition instead."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import audio_fbank_oracle as fb
+
+
+def test_clip_timepoints_match_constant_clips_sampler():
+    assert [(float(a), float(b)) for a, b in fb.clip_timepoints(10.0)] == [(0.0, 2.0), (4.0, 6.0), (8.0, 10.0)]
+    assert [(float(a), float(b)) for a, b in fb.clip_timepoints(2.0)] == [(0.0, 2.0)] * 3
+    assert [(float(a), float(b)) for a, b in fb.clip_timepoints(1.0)] == [(0.0, 2.0)] * 3      # shorter than a clip
+    t = fb.clip_timepoints(5.0)
+    assert [float(a) for a, _ in t] == [0.0, 1.5, 3.0]
+    from hippomm_amd.preprocess import audio_clip_bounds
+    assert audio_clip_bounds(160000) == [(0, 32000), (64000, 96000), (128000, 160000)]
+    assert audio_clip_bounds(16000) == [(0, 16000)] * 3
+    assert audio_clip_bounds(80000) == [(0, 32000), (24000, 56000), (48000, 80000)]
+
+
+def test_frame_count_and_padding():
+    x = torch.randn(1, 32000)
+    assert fb.kaldi_fbank(x).shape == (198, 128)                 # 1 + (32000 - 400) // 160
+    assert fb.kaldi_fbank(torch.randn(1, 399)).shape == (0, 128)
+    assert fb.kaldi_fbank(torch.randn(1, 400)).shape == (1, 128)
+    m = fb.waveform2melspec(x)
+    assert m.shape == (1, 128, 204) and torch.all(m[:, :, 198:] == 0)
+    long = fb.waveform2melspec(torch.randn(1, 40000))            # 248 frames -> cut
+    assert long.shape == (1, 128, 204)
+
+
+def test_mel_banks_are_kaldi_triangles():
+    banks = fb.mel_banks().double()
+    assert banks.shape == (128, 256) and banks.min() >= 0 and banks.max() <= 1
+    # interior FFT bins are covered by exactly two neighbouring triangles whose weights sum to 1
+    mel = 1127.0 * np.log1p(31.25 * np.arange(256) / 700.0)
+    lo, hi = 1127.0 * math.log1p(20 / 700.0), 1127.0 * math.log1p(8000 / 700.0)
+    delta = (hi - lo) / 129
+    inside = (mel > lo + delta) & (mel < hi - delta)
+    np.testing.assert_allclose(banks.sum(0).numpy()[inside], 1.0, atol=2e-5)
+    assert banks[:, 0].sum() == 0                                 # DC is below low_freq = 20 Hz
+    # a filter narrower than one FFT bin can miss every bin: the known empty low bands of the 128-bin / 512-point setup
+    assert int((banks.sum(1) == 0).sum()) >= 1
+
+
+def test_pure_tone_lands_in_the_predicted_band_with_the_predicted_energy():
+    """A sine at an exact FFT bin centre: the windowed, pre-emphasised power spectrum is known in closed form."""
+    k0 = 64                                                       # 2000 Hz
+    n = np.arange(32000)
+    amp = 0.25
+    x = torch.from_numpy((amp * np.sin(2 * np.pi * (k0 * 31.25) * n / 16000.0)).astype(np.float32))[None]
+    got = fb.kaldi_fbank(x)                                       # (198, 128)
+    # closed form in float64 for one frame (all frames are equal up to phase)
+    frame = x[0, :400].double().numpy()
+    frame = frame - frame.mean()
+    pre = frame - 0.97 * np.concatenate([frame[:1], frame[:-1]])
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(400) / 399)
+    spec = np.abs(np.fft.rfft(pre * win, 512)) ** 2
+    banks = np.pad(fb.mel_banks().double().numpy(), ((0, 0), (0, 1)))
+    want = np.log(np.maximum(banks @ spec, np.finfo(np.float32).eps))
+    np.testing.assert_allclose(got[0].double().numpy(), want, rtol=0, atol=2e-3)
+    top = int(got.mean(0).argmax())
+    mel_k0 = 1127.0 * math.log1p(2000.0 / 700.0)
+    lo, hi = 1127.0 * math.log1p(20 / 700.0), 1127.0 * math.log1p(8000 / 700.0)
+    assert abs(top - ((mel_k0 - lo) / ((hi - lo) / 129) - 1)) <= 1.0   # centre of triangle `top` is nearest the tone
+
+
+def test_full_transform_shape_and_normalisation():
+    w = torch.randn(1, 16000 * 7, generator=torch.Generator().manual_seed(0)) * 0.1
+    out = fb.load_and_transform_audio(w)
+    assert out.shape == (3, 1, 128, 204)
+    assert torch.allclose(out[:, :, :, 198:], torch.full((3, 1, 128, 6), (0 + 4.268) / 9.138))
+    with pytest.raises(ValueError):
+        fb.load_and_transform_audio(w, 44100)
+
+
+def test_read_wav_round_trip(tmp_path):
+    from scipy.io import wavfile
+    from hippomm_amd.preprocess import read_wav
+    x = np.clip(np.random.default_rng(0).standard_normal(5000) * 0.3, -0.99, 0.99).astype(np.float32)
+    wavfile.write(tmp_path / "f32.wav", 16000, x)                 # as hippocampal_memory.py:1219
+    got, rate = read_wav(str(tmp_path / "f32.wav"))
+    assert rate == 16000 and got.shape == (1, 5000) and np.array_equal(got[0], x)
+    wavfile.write(tmp_path / "s16.wav", 16000, (x * 32767).astype(np.int16))   # as ffmpeg pcm_s16le
+    got, _ = read_wav(str(tmp_path / "s16.wav"))
+    np.testing.assert_allclose(got[0], x, atol=2.0 / 32768 + 1e-5)       # truncation + the 32767/32768 scale
+
+
+# ------------------------------------------------------------------------------------------ float64 evaluation
+def f64_melspec(w: torch.Tensor):
+    """The same definition evaluated in float64 (numpy FFT) with the float32 window-free formulas; returns the
+    normalised (3,1,128,204) tensor and, per clip, the band energies (frames,128) for energy-aware tolerances."""
+    banks = np.pad(fb.mel_banks().double().numpy(), ((0, 0), (0, 1)))
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(400) / 399)
+    outs, energies = [], []
+    x_all = w.double().numpy()
+    for start, end in fb.clip_timepoints(x_all.shape[1] / 16000):
+        x = x_all[0, int(start * 16000): int(end * 16000)]
+        x = x - (x_all[:, int(start * 16000): int(end * 16000)]).mean()
+        m = 1 + (len(x) - 400) // 160 if len(x) >= 400 else 0
+        mel = np.zeros((128, 204))
+        e = np.zeros((0, 128))
+        if m > 0:
+            fr = np.lib.stride_tricks.sliding_window_view(x, 400)[::160][:m]
+            fr = fr - fr.mean(1, keepdims=True)
+            fr = fr - 0.97 * np.concatenate([fr[:, :1], fr[:, :-1]], 1)
+            spec = np.abs(np.fft.rfft(fr * win, 512, axis=1)) ** 2
+            e = spec @ banks.T
+            lg = np.log(np.maximum(e, np.finfo(np.float32).eps))
+            mel[:, :min(m, 204)] = lg.T[:, :204]
+        outs.append((mel[None] + 4.268) / 9.138)
+        energies.append(e[:204])
+    return torch.from_numpy(np.stack(outs)), energies
+
+
+def assert_melspec_close(got: torch.Tensor, w: torch.Tensor, what: str):
+    """fp32 transforms (the oracle's FFT as much as the kernel's direct DFT) carry an absolute error of ~1e-7 of the
+    frame's LARGEST spectral line, so a band 60 dB below the frame maximum is only good to ~1e-3 relative.  Tolerance on
+    the normalised log-mel: 1e-4 where the band holds >= 1e-5 of the frame's strongest band, 3e-3 below that
+    (bands with no FFT bin at all sit at log(eps) exactly)."""
+    ref, energies = f64_melspec(w)
+    err = (got.double() - ref).abs()
+    worst_solid = worst_weak = 0.0
+    for c, e in enumerate(energies):
+        m = e.shape[0]
+        if m == 0:
+            continue
+        solid = torch.from_numpy(e >= 1e-5 * e.max(1, keepdims=True)).T            # (128, m)
+        ec = err[c, 0, :, :m]
+        worst_solid = max(worst_solid, ec[solid].max().item() if solid.any() else 0.0)
+        worst_weak = max(worst_weak, ec[~solid].max().item() if (~solid).any() else 0.0)
+        assert err[c, 0, :, m:].max().item() <= 1e-6 if m < 204 else True            # zero padding, exactly
+    print(f"{what}: worst |diff| vs float64 -- solid bands {worst_solid:.2e}, weak bands {worst_weak:.2e}")
+    assert worst_solid <= 1e-4 and worst_weak <= 3e-3
+
+
+@pytest.mark.parametrize("seconds,kind", [(10.0, "noise"), (7.3, "tones"), (1.0, "noise")])
+def test_oracle_matches_float64_evaluation(seconds, kind):
+    w = _wave(seconds, kind)
+    assert_melspec_close(fb.load_and_transform_audio(w), w, f"oracle {seconds}s {kind}")
+
+
+def _wave(seconds, kind):
+    n = int(seconds * 16000)
+    g = torch.Generator().manual_seed(n)
+    if kind == "noise":
+        return torch.randn(1, n, generator=g) * 0.2 + 0.05               # with a DC offset
+    t = torch.arange(n) / 16000.0
+    return (0.3 * torch.sin(2 * math.pi * 440.0 * t) + 0.1 * torch.sin(2 * math.pi * 3333.0 * t)
+            + 0.01 * torch.randn(n, generator=g))[None]
+
+
+# ------------------------------------------------------------------------------------------ GPU parity
+@pytest.mark.gpu
+@pytest.mark.parametrize("seconds,kind", [(10.0, "noise"), (2.0, "noise"), (7.3, "tones"), (1.0, "noise"), (0.02, "noise")])
+def test_hip_fbank_matches_oracle(seconds, kind):
+    from hippomm_amd.preprocess import transform_waveforms_device
+    w = _wave(seconds, kind)
+    want = fb.load_and_transform_audio(w)
+    got = transform_waveforms_device([w], torch.device("cuda"))[0].cpu()
+    assert got.shape == (3, 1, 128, 204)
+    assert_melspec_close(got, w, f"hip {seconds}s {kind}")
+    assert (got - want).abs().max().item() <= 3e-3                    # and against the fp32 oracle itself
+
+
+@pytest.mark.gpu
+def test_hip_fbank_generated_tables_close_to_host_tables():
+    """Null window / bank pointers: the library generates the tables on the device.  Same formulas, but the device
+    log() differs from the host's in the last bit, which only matters for triangles that barely touch an FFT bin:
+    compare on the bands whose energy is not ~0."""
+    import ctypes as C
+    from hippomm_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    clips = (torch.randn(2, 32000, generator=g) * 0.2).cuda()
+    ws = torch.empty(lib.hmm_audio_fbank_workspace_bytes(2), dtype=torch.uint8, device="cuda")
+    out = torch.empty(2, 128, 204, device="cuda")
+    L.check(lib.hmm_audio_fbank(clips.data_ptr(), 2, 32000, 32000, None, None, -4.268, 9.138, out.data_ptr(),
+                                ws.data_ptr(), ws.numel(), L.stream_ptr()), "fbank")
+    from hippomm_amd.preprocess import melspec_clips_device
+    ref = melspec_clips_device(clips)
+    solid = fb.mel_banks().sum(1) > 0.05                         # bands with real support
+    assert (out[:, solid] - ref[:, solid]).abs().max().item() <= 1e-4
+    assert torch.isfinite(out).all()
+    # argument checks
+    assert lib.hmm_audio_fbank(clips.data_ptr(), 2, 32000, 100, None, None, -4.268, 9.138, out.data_ptr(),
+                               ws.data_ptr(), ws.numel(), L.stream_ptr()) != 0
+    assert lib.hmm_audio_fbank(clips.data_ptr(), 2, 32000, 32000, None, None, -4.268, 9.138, out.data_ptr(),
+                               ws.data_ptr(), 16, L.stream_ptr()) != 0 and b"workspace" in lib.hmm_last_error()
+
+
+@pytest.mark.gpu
+def test_hip_fbank_silence_and_batching():
+    """All-zero input takes the max(energy, eps) branch; several files of different lengths in one call."""
+    from hippomm_amd.preprocess import transform_waveforms_device
+    g = torch.Generator().manual_seed(3)
+    waves = [torch.zeros(1, 32000), torch.randn(2, 48000, generator=g) * 0.1, torch.randn(20000, generator=g) * 0.1]
+    got = transform_waveforms_device(waves, torch.device("cuda")).cpu()
+    assert got.shape == (3, 3, 1, 128, 204)
+    want0 = fb.load_and_transform_audio(waves[0])
+    assert torch.allclose(got[0], want0, atol=1e-6)              # log(eps) rows, zero padding
+    assert_melspec_close(got[1], waves[1][:1], "batched file 1 (channel 0)")
+    assert_melspec_close(got[2], waves[2][None], "batched file 2")
+
+
+@pytest.mark.gpu
+def test_imagebind_load_data_accepts_wav_paths(tmp_path):
+    """foundation_models.py:93-109: {'audio': [path]} -> (B,3,1,128,204) on the device."""
+    from scipy.io import wavfile
+    from hippomm_amd.encoder import ImageBind, synthetic_state_dict
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(16000 * 4, generator=g) * 0.2).numpy().astype(np.float32)
+    wavfile.write(tmp_path / "seg.wav", 16000, w)
+    model = ImageBind(state_dict=synthetic_state_dict(("audio",), depth={"audio": 1}), towers=("audio",), depth={"audio": 1})
+    data = model.load_data({"audio": [str(tmp_path / "seg.wav")]}, ["audio"])
+    assert data["audio"].shape == (1, 3, 1, 128, 204) and data["audio"].is_cuda
+    assert_melspec_close(data["audio"][0].cpu(), torch.from_numpy(w)[None], "load_data wav path")
+    feats = model.extract_features({"audio": [str(tmp_path / "seg.wav")]}, ["audio"])["audio"]
+    assert feats.shape == (1, 1024) and torch.isfinite(feats).all()
+    # wrong sample rate: logged and skipped like any per-modality failure (:110-112)
+    wavfile.write(tmp_path / "bad.wav", 44100, w)
+    assert "audio" not in model.load_data({"audio": [str(tmp_path / "bad.wav")]}, ["audio"])
