@@ -238,6 +238,11 @@ class ImageBind(nn.Module):
                  tokenizer=None):
         super().__init__()
         self.tokenizer = tokenizer                  # str list -> (B,77) int64 (imagebind.data.load_and_transform_text)
+        if self.tokenizer is None and "text" in tuple(towers):
+            from .tokenizer import SimpleTokenizer, find_bpe_vocab     # upstream's merge table, if it is on disk
+            bpe = find_bpe_vocab(model_path)
+            if bpe is not None:
+                self.tokenizer = SimpleTokenizer(str(bpe))
         self.device = _lib.require_gpu()            # reference :26 falls back to cpu then calls .cuda() anyway (:33)
         self.model = self._load_model(model_path, state_dict, tuple(towers), depth or {},
                                       max_batch or {"vision": 256, "audio": 128})
@@ -291,8 +296,9 @@ class ImageBind(nn.Module):
                     transformed[modality] = load_and_transform_audio_data_device(paths, self.device)
                 elif modality == ModalityType.TEXT:
                     if self.tokenizer is None:
-                        raise NotImplementedError("text needs a CLIP-BPE tokenizer (tokenizer= callable) or a "
-                                                  "(B,77) int64 token tensor; the vocabulary file is not shipped")
+                        raise NotImplementedError("text needs the CLIP merge table bpe_simple_vocab_16e6.txt.gz (under "
+                                                  "model_path, .checkpoints/, bpe/ or $IMAGEBIND_BPE), a tokenizer= "
+                                                  "callable, or a (B,77) int64 token tensor")
                     transformed[modality] = self.tokenizer(list(value)).to(self.device)
                 else:
                     raise NotImplementedError(f"modality {modality!r} is not built")
