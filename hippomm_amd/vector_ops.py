@@ -11,7 +11,7 @@ call, which is correct but PCIe-bound.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Tuple, Union
+from typing import List, Tuple, Union
 
 import numpy as np
 import torch
@@ -99,6 +99,34 @@ class FeatureStore:
                                                  counts.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
                                                  _lib.stream_ptr()), "hmm_cosine_topk_segmented")
         return idx, sims, counts
+
+    def search_multi_device(self, queries: torch.Tensor, k: int):
+        """queries (Q,1024) fp32 on the store's device -> (idx (Q,k') int64, sims (Q,k') fp32) device tensors,
+        k' = min(k, N).  One pass over the store per 16 queries (hmm_cosine_topk_multi)."""
+        if queries.dim() != 2 or queries.shape[1] != FEATURE_DIM:
+            raise ValueError(f"queries must be (Q,{FEATURE_DIM}), got {tuple(queries.shape)}")
+        queries = queries.to(device=self.rows.device, dtype=torch.float32).contiguous()
+        nq, n = queries.shape[0], len(self)
+        if nq == 0:
+            raise ValueError("no queries")
+        lib = _lib.load()
+        need = lib.hmm_cosine_topk_multi_workspace_bytes(n, nq, k)
+        ws = torch.empty(need, dtype=torch.uint8, device=self.rows.device)
+        idx = torch.empty(nq, k, dtype=torch.int64, device=self.rows.device)
+        sims = torch.empty(nq, k, dtype=torch.float32, device=self.rows.device)
+        n_out = torch.empty(nq, dtype=torch.int32, device=self.rows.device)
+        _lib.check(lib.hmm_cosine_topk_multi(self.rows.data_ptr(), n, FEATURE_DIM, queries.data_ptr(), nq, k,
+                                                   idx.data_ptr(), sims.data_ptr(), n_out.data_ptr(), ws.data_ptr(),
+                                                   ws.numel(), _lib.stream_ptr()), "hmm_cosine_topk_multi")
+        kk = min(k, n)
+        return idx[:, :kk], sims[:, :kk]
+
+    def search_multi(self, queries, k: int) -> List[Tuple[np.ndarray, np.ndarray]]:
+        """Per query the (indices int64, similarities) pair top_k_cosine_similarity would return."""
+        q = queries if isinstance(queries, torch.Tensor) else torch.from_numpy(np.asarray(queries, dtype=np.float32))
+        idx, sims = self.search_multi_device(q.reshape(-1, FEATURE_DIM), k)
+        idx, sims = idx.cpu().numpy(), sims.cpu().numpy()
+        return [(idx[i], sims[i]) for i in range(idx.shape[0])]
 
     def search(self, query, k: int) -> Tuple[np.ndarray, np.ndarray]:
         q = _query_to_device(query, self.rows.device)

@@ -73,6 +73,18 @@ int    hmm_topk_merge_keys(const uint64_t* keys_dev /* [n_shards][k] */, int n_s
                            int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
                            hmm_stream_t stream);
 
+/* Batched feature_search: the top-k of n_queries queries against the same store in ONE pass over it
+ * (16 queries per pass; the Q x rows similarity block runs on the fp32 matrix cores, so a row is still read once from
+ * HBM).  The reference calls top_k_cosine_similarity once per question (hippomm/utils/vector_ops.py:151-188 via
+ * hippocampal_memory.py:3153, :3304).  queries_dev (n_queries,1024) fp32 row-major.  Outputs are row-major with row
+ * stride k: idx_out[q*k ..], sim_out[q*k ..] (the first min(k, n_rows) entries of a row are valid), n_out[q].
+ * Same similarity, total order and tie rule as hmm_cosine_topk (results can differ from it only where two similarities
+ * agree to fp32 rounding: the dot products are summed in a different order).  k > 64 falls back to one scan per query. */
+size_t hmm_cosine_topk_multi_workspace_bytes(int64_t n_rows, int n_queries, int k);
+int    hmm_cosine_topk_multi(const float* store_dev, int64_t n_rows, int dim, const float* queries_dev, int n_queries,
+                             int k, int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
+                             void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
+
 /* Per-event feature_search in one pass.  Replaces the Python loop over events that calls
  * top_k_cosine_similarity(query, event.features[...], k=5) once per event
  * (hippomm/core/hippocampal_memory.py:3143-3153, :3294-3304).  store_dev is the concatenation of the
