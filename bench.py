@@ -114,6 +114,12 @@ def scan_bench(do_cpu):
                      "traffic": 4096643072, "traffic_source": "profiles/r1_scan_pmc_summary.json",
                      "bytes_per_launch": algo_bytes, "ms_per_launch": round(ms_kernel, 4)},
     }
+    # batched questions: 16 queries per pass over the same store
+    q16 = torch.randn(16, 1024, generator=torch.Generator(device="cuda").manual_seed(44), device="cuda")
+    ms_multi = event_time_ms(lambda: store.search_multi_device(q16, SCAN_K), 10, warmup=3)
+    out["batched_16_queries"] = {"ms_per_pass": round(ms_multi, 4), "us_per_query": round(ms_multi / 16 * 1e3, 1),
+                                 "store_read_GBps": round(algo_bytes / ms_multi / 1e6, 1),
+                                 "speedup_vs_16_single_scans": round(16 * ms_query / ms_multi, 2)}
     if do_cpu:
         from oracle.vector_ops_oracle import top_k_cosine_similarity_oracle
         n_cpu = 200_000
