@@ -37,16 +37,23 @@ struct MultiLds {
     int cnt[kMQ];
 };
 
-// descending bitonic sort of n2 (power of two, <= kMCap) keys by ONE wave
-__device__ __forceinline__ void wave_bitonic_desc(uint64_t* s, int n2, int lane) {
+// Descending bitonic sort, by ONE wave, of the first n2 (power of two, <= kMCap) keys of NL lists at once: the lists'
+// compare-exchange steps are independent, so walking them in lockstep overlaps their LDS round trips (a single
+// list is latency-bound: ~26 us for 512 keys).
+template <int NL>
+__device__ __forceinline__ void wave_bitonic_desc(uint64_t* (&s)[NL], int n2, int lane) {
     for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = lane; t < (n2 >> 1); t += 64) {
                 const int i = 2 * t - (t & (j - 1));
                 const int l = i + j;
                 const bool desc = (i & k) == 0;
-                const uint64_t a = s[i], b = s[l];
-                if ((a < b) == desc) { s[i] = b; s[l] = a; }
+                uint64_t a[NL], b[NL];
+#pragma unroll
+                for (int q = 0; q < NL; ++q) { a[q] = s[q][i]; b[q] = s[q][l]; }
+#pragma unroll
+                for (int q = 0; q < NL; ++q)
+                    if ((a[q] < b[q]) == desc) { s[q][i] = b[q]; s[q][l] = a[q]; }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -83,30 +90,22 @@ __global__ __launch_bounds__(kMWaves * 64) void scan_multi_kernel(const float* _
     const float* qb = &L.q[r16 * kMQStride + 8 * g];            // + 32*i (+4): this lane's B fragments
 
     const int64_t n_chunks = (n_rows + kMRows - 1) / kMRows;
-    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const int64_t row0 = chunk * kMRows + wave * (kMTiles * 16);     // this wave's 64 rows
-        // A operand: lane (r16, g) reads row r16 of each tile, columns 32*i + 8*g .. +7
-        const float* a_ptr[kMTiles];
+    constexpr int STAGES = 4;                                     // register ring: 3 steps of loads in flight (8 measured slower)
+    f32x4 a[STAGES][kMTiles][2];
+    const float* a_ptr[kMTiles];
+    int rot = 0;
+    // A operand: lane (r16, g) reads row r16 of each tile, columns 32*i + 8*g .. +7.  Every wave walks K from a different
+    // starting step: the 16 rows of a tile are 4 KiB apart, so at any moment a wave asks for the same 128-B column of 16
+    // rows; rotating the walk spreads concurrent waves over the columns.
+    auto begin_chunk = [&](int64_t chunk) {                       // row pointers + the first STAGES-1 steps of loads
+        const int64_t row0 = chunk * kMRows + wave * (kMTiles * 16);
 #pragma unroll
         for (int t = 0; t < kMTiles; ++t) {
             int64_t r = row0 + 16 * t + r16;
             r = r < n_rows ? r : n_rows - 1;
             a_ptr[t] = store + r * 1024 + 8 * g;
         }
-        // the query fragments are invariant across chunks: without this opaque zero the compiler hoists all 64 LDS
-        // reads (256 registers) out of the chunk loop and spills
-        int zv;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(zv));
-        const float* qbi = qb + zv;
-        // every wave walks K from a different starting step: the 16 rows of a tile are 4 KiB apart, so at any moment a
-        // wave asks for the same 128-B column of 16 rows; rotating the walk spreads concurrent waves over the columns
-        const int rot = g_multi_rot ? (int)((chunk * kMWaves + wave) * 5) & 31 : 0;
-        f32x4 acc[kMTiles];
-        float ss[kMTiles];
-#pragma unroll
-        for (int t = 0; t < kMTiles; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ss[t] = 0.f; }
-        constexpr int STAGES = 4;                                 // register ring: 3 steps of loads in flight (8 measured slower)
-        f32x4 a[STAGES][kMTiles][2];
+        rot = (g_multi_rot & 1) ? (int)((chunk * kMWaves + wave) * 5) & 31 : 0;
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
 #pragma unroll
@@ -114,23 +113,39 @@ __global__ __launch_bounds__(kMWaves * 64) void scan_multi_kernel(const float* _
                 a[s][t][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_ptr[t] + 32 * ((s + rot) & 31)));
                 a[s][t][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_ptr[t] + 32 * ((s + rot) & 31) + 4));
             }
+    };
+    if ((int64_t)blockIdx.x < n_chunks) begin_chunk(blockIdx.x);
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int64_t row0 = chunk * kMRows + wave * (kMTiles * 16);     // this wave's 64 rows
+        // the query fragments are invariant across chunks: without this opaque zero the compiler hoists all 64 LDS
+        // reads (256 registers) out of the chunk loop and spills
+        int zv;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zv));
+        const float* qbi = qb + zv;
+        const bool abl_nomfma = g_multi_rot & 2, abl_noselect = g_multi_rot & 4;      // timing ablations (wrong results)
+        f32x4 acc[kMTiles];
+        float ss[kMTiles];
+#pragma unroll
+        for (int t = 0; t < kMTiles; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ss[t] = 0.f; }
+        const int rot_cur = rot;
 #pragma unroll 4
         for (int i = 0; i < 32; ++i) {                            // unrolled by STAGES: ring slots are compile-time
             const int cur = i % STAGES, nxt = (i + STAGES - 1) % STAGES;
             if (i + STAGES - 1 < 32) {
 #pragma unroll
                 for (int t = 0; t < kMTiles; ++t) {
-                    a[nxt][t][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_ptr[t] + 32 * ((i + STAGES - 1 + rot) & 31)));
-                    a[nxt][t][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_ptr[t] + 32 * ((i + STAGES - 1 + rot) & 31) + 4));
+                    a[nxt][t][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_ptr[t] + 32 * ((i + STAGES - 1 + rot_cur) & 31)));
+                    a[nxt][t][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_ptr[t] + 32 * ((i + STAGES - 1 + rot_cur) & 31) + 4));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);                     // keep the prefetch depth at STAGES - 1 steps
-            const float4 b0 = *reinterpret_cast<const float4*>(qbi + 32 * ((i + rot) & 31));
-            const float4 b1 = *reinterpret_cast<const float4*>(qbi + 32 * ((i + rot) & 31) + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(qbi + 32 * ((i + rot_cur) & 31));
+            const float4 b1 = *reinterpret_cast<const float4*>(qbi + 32 * ((i + rot_cur) & 31) + 4);
 #pragma unroll
             for (int t = 0; t < kMTiles; ++t) {
                 const f32x4 x0v = a[cur][t][0], x1v = a[cur][t][1];
                 const float4 x0 = make_float4(x0v[0], x0v[1], x0v[2], x0v[3]), x1 = make_float4(x1v[0], x1v[1], x1v[2], x1v[3]);
+                if (abl_nomfma) { ss[t] += (x0.x + x0.y) + (x1.z + x1.w); continue; }
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, b0.x, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, b0.y, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, b0.z, acc[t], 0, 0, 0);
@@ -145,6 +160,8 @@ __global__ __launch_bounds__(kMWaves * 64) void scan_multi_kernel(const float* _
                 ss[t] = fmaf(x1.z, x1.z, ss[t]); ss[t] = fmaf(x1.w, x1.w, ss[t]);
             }
         }
+        // the next chunk's first loads fly during the selection below (the ring is free again)
+        if (chunk + gridDim.x < n_chunks) begin_chunk(chunk + gridDim.x);
         // row norms: the four lanes (r16, g = 0..3) of a row hold its partial sums
 #pragma unroll
         for (int t = 0; t < kMTiles; ++t) {
@@ -159,28 +176,43 @@ __global__ __launch_bounds__(kMWaves * 64) void scan_multi_kernel(const float* _
                 const int64_t row = row0 + 16 * t + 4 * g + j;
                 const float sim = acc[t][j] / (rn * my_qlen);
                 const uint64_t key = ((uint64_t)order_bits(sim) << 32) | (uint64_t)(uint32_t)row;
-                if (r16 < n_q && row < n_rows && key > L.tau[r16]) {
+                if (r16 < n_q && row < n_rows && key > L.tau[r16] && !abl_noselect) {
                     const int pos = atomicAdd(&L.cnt[r16], 1);
                     L.keys[r16][pos] = key;
                 }
             }
         }
         __syncthreads();
-        bool need = chunk + gridDim.x >= n_chunks;                // last iteration of this workgroup
+        // Sort the lists down to k: at the end, whenever one could overflow in the next iteration, and once after the very
+        // first iteration -- that sets the thresholds early, so that from the second iteration on only rows that beat the
+        // current k-th best are appended at all.
+        bool need = chunk + gridDim.x >= n_chunks || chunk == (int64_t)blockIdx.x;
 #pragma unroll
         for (int qi = 0; qi < kMQ; ++qi) need |= L.cnt[qi] > kMCap - kMRows;
         if (need) {                                               // workgroup-uniform
-            for (int qi = wave; qi < n_q; qi += kMWaves) {
-                const int n = L.cnt[qi];
-                int n2 = 64;
-                while (n2 < n) n2 <<= 1;
-                for (int t = n + lane; t < n2; t += 64) L.keys[qi][t] = 0ull;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                wave_bitonic_desc(L.keys[qi], n2, lane);
-                if (lane == 0) {
-                    L.cnt[qi] = n < k ? n : k;
-                    L.tau[qi] = n >= k ? L.keys[qi][k - 1] : 0ull;
+            constexpr int NL = kMQ / kMWaves;                     // lists per wave: wave w owns queries w, w + 4, ...
+            uint64_t* lists[NL];
+            int n[NL], nmax = 0;
+#pragma unroll
+            for (int q = 0; q < NL; ++q) {
+                lists[q] = L.keys[wave + q * kMWaves];
+                n[q] = L.cnt[wave + q * kMWaves];
+                nmax = n[q] > nmax ? n[q] : nmax;
+            }
+            int n2 = 64;
+            while (n2 < nmax) n2 <<= 1;
+#pragma unroll
+            for (int q = 0; q < NL; ++q)
+                for (int t = n[q] + lane; t < n2; t += 64) lists[q][t] = 0ull;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            wave_bitonic_desc<NL>(lists, n2, lane);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < NL; ++q) {
+                    const int qi = wave + q * kMWaves;
+                    L.cnt[qi] = n[q] < k ? n[q] : k;
+                    L.tau[qi] = n[q] >= k ? lists[q][k - 1] : 0ull;
                 }
             }
             __syncthreads();

@@ -10,9 +10,9 @@ for s in range(0, N, 65536):
     rows[s:s + 65536] = torch.nn.functional.normalize(torch.randn(min(65536, N - s), 1024, device="cuda", generator=g), dim=1)
 fs = FeatureStore(rows)
 from hippomm_amd import _lib
-for rot in (0, 1):
+for rot in (1, 5):
   _lib.load().hmm_dev_set_multi_rotate(rot)
-  print("rotate K walk:", rot)
+  print("flags (1 rotate, 2 no MFMA, 4 no selection):", rot)
   for nq, k in [(1, 32), (16, 32), (16, 5), (32, 32)]:
     q = torch.randn(nq, 1024, device="cuda", generator=g)
     for _ in range(3): fs.search_multi_device(q, k)
