@@ -312,7 +312,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
 template <int EPI, int F = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    void* __restrict__ Cout, int M, int N, int K, int tiles_n) {
+    void* __restrict__ Cout, int M, int N, int K, int tiles_n, int g_tile_group_n) {
     // F: experiment flags (0 in production).  1: P1 waits only for its kh=0 fragments before the
     // barrier; 2: no s_setprio; 4: no stagger between the wave groups; 8: ablation, no in-loop DMA;
     // 16: ablation, no in-loop LDS reads (8 and 16 give wrong results; timing only).
@@ -338,7 +338,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const int nb = gridDim.x, bid = blockIdx.x;
     const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int m0 = (swz / tiles_n) * 256, n0 = (swz % tiles_n) * 256;
+    // Tile walk inside the XCD's range: column groups of gn tiles, row-major inside a group (gn = tiles_n: plain strips
+    // of whole row tiles, the default).  PMC shows the strip order pulling all of W through the fabric once per row tile
+    // (3.4 GB per fc1 GEMM for 0.85 GB of algorithmic traffic), and with gn = 4 an isolated qkv GEMM runs at 1214 instead
+    // of 995 TFLOP/s -- but inside the tower, where the activations were just written by the previous kernel and sit in
+    // the Infinity Cache, the grouped walk re-reads them tiles_n / gn times and writes 2-KiB row pieces: every GEMM is
+    // 3-7 % SLOWER in situ (rocprof, same process: qkv 520 -> 558 us, fc1 811 -> 832 us; forward 90.6 -> 93.7 ms).
+    const int gn = g_tile_group_n > 0 && g_tile_group_n < tiles_n ? g_tile_group_n : tiles_n;
+    const int tiles_m = nb / tiles_n, per_group = gn * tiles_m;
+    const int grp = swz / per_group, rem = swz - grp * per_group;
+    const int first = grp * gn, width = tiles_n - first < gn ? tiles_n - first : gn;      // the last group may be narrower
+    const int m0 = (rem / width) * 256, n0 = (first + rem % width) * 256;
     if constexpr (F_DEPHASE) {
         if (bid < 2 * kNumCU)
             for (int i = 0; i < xcd; ++i) __builtin_amdgcn_s_sleep(47);
@@ -561,6 +571,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 }
 
 
+int g_gemm_tile_group = -1;    // tuning hook: -1 auto, 0 strip order, n = column groups of n tiles
+
 template <int EPI, int F = 0>
 static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, hipStream_t st) {
     constexpr int LDS = (8 * kEpiSlab > 2 * 4 * 16384 ? 8 * kEpiSlab : 2 * 4 * 16384) + 8 * 256;   // + residual-prefetch sink
@@ -572,7 +584,9 @@ static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
         attr_set = true;
     }
     const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
-    kern<<<tiles_m * tiles_n, 512, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n);
+    int gn = g_gemm_tile_group;
+    if (gn < 0) gn = 0;      // 0 = one group (strip order): the default, see the kernel's comment on the tile walk
+    kern<<<tiles_m * tiles_n, 512, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n, gn);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
@@ -706,3 +720,4 @@ extern "C" int hmm_dev_gemm_bf16_variant(const uint16_t* a_dev, const uint16_t* 
                      M, N, K, epilogue, variant, static_cast<hipStream_t>(stream));
 }
 extern "C" void hmm_dev_set_gemm_variant(int variant) { g_gemm_default_variant = variant; }
+extern "C" void hmm_dev_set_gemm_tile_group(int gn) { hmm::g_gemm_tile_group = gn; }

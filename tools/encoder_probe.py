@@ -20,7 +20,9 @@ out = torch.empty(B, 1024, device="cuda")
 import itertools
 streams = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [2]
 lnb = [int(v) for v in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0]
-for v, ns, lb in itertools.product(variants, streams, lnb):
+tgs = [int(v) for v in sys.argv[6].split(",")] if len(sys.argv) > 6 else [-1]
+for v, ns, lb, tg in itertools.product(variants, streams, lnb, tgs):
+    lib.hmm_dev_set_gemm_tile_group(tg)
     lib.hmm_dev_set_gemm_variant(v)
     lib.hmm_dev_set_encoder_streams(ns)
     lib.hmm_dev_set_ln_max_blocks(lb)
@@ -33,6 +35,6 @@ for v, ns, lb in itertools.product(variants, streams, lnb):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / it
     fl = tower.flops(B)
-    print(f"{tower_name} B={B} gemm_variant={v} streams={ns} ln_blocks={lb}: {ms:.2f} ms/forward  {B/ms*1e3:.1f} samples/s  "
+    print(f"{tower_name} B={B} gemm_variant={v} streams={ns} ln_blocks={lb} tile_group={tg}: {ms:.2f} ms/forward  {B/ms*1e3:.1f} samples/s  "
           f"{fl/ms/1e9:.0f} TFLOP/s ({fl/ms/1e9/2500*100:.1f}% of 2.5 PF)", flush=True)
 print("out finite:", bool(torch.isfinite(out).all()), "norm", float(out.norm(dim=1).mean()))
