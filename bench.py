@@ -81,6 +81,13 @@ def gemm_roofline(rows):
     roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
             "flops_per_launch": 2.0 * dom["M"] * dom["N"] * dom["K"], "ms_per_launch": dom["ms"]}
+    if dom["kernel"] == "gemm_bf16[mlp_fc1+gelu]" and rows == 65792:
+        # PMC passes (profiles/r1_gemm_pmc_summary.json): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, main + peeled
+        # launch.  These are fabric-side requests, Infinity-Cache hits included: 4.9x the operand bytes because the strip
+        # tile walk streams the 13-MB weight matrix once per 256-row tile (cache traffic, the kernel is MFMA-bound).
+        roof["traffic"] = 4156223882
+        roof["traffic_source"] = "profiles/r1_gemm_pmc_summary.json"
+        roof["algorithmic_bytes_per_launch"] = 2 * (rows * 1280 + 5120 * 1280 + rows * 5120)
     return roof, table
 
 
