@@ -195,6 +195,32 @@ def test_hip_fbank_generated_tables_close_to_host_tables():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("clip_len", [64000, 32123, 400, 399, 33000])
+def test_hip_fbank_clip_lengths(clip_len):
+    """Clips that are not 2 s long: more than 204 frames are cut, fewer are zero-padded, < 400 samples give no frame."""
+    from hippomm_amd.preprocess import melspec_clips_device
+    g = torch.Generator().manual_seed(clip_len)
+    clips = torch.randn(5, clip_len, generator=g) * 0.3
+    got = melspec_clips_device(clips.cuda()).cpu()
+    for c in range(5):
+        want = (fb.waveform2melspec(clips[c:c + 1].clone()) + 4.268) / 9.138
+        assert (got[c] - want[0]).abs().max().item() <= 3e-3
+    n_frames = max(0, 1 + (clip_len - 400) // 160) if clip_len >= 400 else 0
+    if n_frames < 204:
+        assert torch.allclose(got[:, :, n_frames:], torch.full((5, 128, 204 - n_frames), 4.268 / 9.138))
+
+
+@pytest.mark.gpu
+def test_hip_fbank_many_clips():
+    from hippomm_amd.preprocess import melspec_clips_device
+    clips = torch.randn(3000, 32000, generator=torch.Generator().manual_seed(1)) * 0.1
+    got = melspec_clips_device(clips.cuda())
+    assert got.shape == (3000, 128, 204) and torch.isfinite(got).all()
+    want = (fb.waveform2melspec(clips[2999:3000].clone()) + 4.268) / 9.138
+    assert (got[2999].cpu() - want[0]).abs().max().item() <= 3e-3
+
+
+@pytest.mark.gpu
 def test_hip_fbank_silence_and_batching():
     """All-zero input takes the max(energy, eps) branch; several files of different lengths in one call."""
     from hippomm_amd.preprocess import transform_waveforms_device

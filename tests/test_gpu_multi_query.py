@@ -17,7 +17,7 @@ def _unit_rows(n, seed):
 
 
 @pytest.mark.parametrize("n,nq,k", [(5000, 3, 5), (4097, 16, 32), (70000, 7, 5), (300, 16, 5), (1, 2, 5), (255, 1, 64),
-                                    (20000, 33, 8), (9000, 17, 64)])
+                                    (20000, 33, 8), (9000, 17, 64), (257, 5, 1), (513, 16, 3)])
 def test_multi_query_matches_oracle(n, nq, k):
     from hippomm_amd.vector_ops import FeatureStore
     store = _unit_rows(n, n + nq)
