@@ -104,15 +104,31 @@ def preprocess_frames_device(frames_u8: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def load_and_transform_vision_data_device(image_paths: Sequence[str], device=None) -> torch.Tensor:
-    """Decode on the host (PIL), resize / crop / normalise on the GPU.  Frames are grouped by size so that the
-    frames of one video go through a single launch."""
+def decode_rgb(image_paths: Sequence[str], workers: int = 0) -> List[np.ndarray]:
+    """Paths -> uint8 (H,W,3) arrays in the given order.  JPEG/PNG decoding is the one step left on the host; Pillow's
+    decoders release the GIL, so a small thread pool scales it with the cores (the resize that used to dominate the
+    host time -- 9 ms per 1080p frame -- now runs on the GPU).  workers = 0: min(8, cpu count); 1: sequential."""
     from PIL import Image
-    dev = device or _lib.require_gpu()
-    decoded: List[np.ndarray] = []
-    for path in image_paths:
+
+    def one(path):
         with open(path, "rb") as fh:
-            decoded.append(np.asarray(Image.open(fh).convert("RGB"), dtype=np.uint8))
+            return np.asarray(Image.open(fh).convert("RGB"), dtype=np.uint8)
+
+    if workers <= 0:
+        import os
+        workers = min(8, os.cpu_count() or 1)
+    if workers == 1 or len(image_paths) < 4:
+        return [one(p) for p in image_paths]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        return list(pool.map(one, image_paths))
+
+
+def load_and_transform_vision_data_device(image_paths: Sequence[str], device=None, workers: int = 0) -> torch.Tensor:
+    """Decode on the host (PIL, thread pool), resize / crop / normalise on the GPU.  Frames are grouped by size so that
+    the frames of one video go through a single launch."""
+    dev = device or _lib.require_gpu()
+    decoded = decode_rgb(image_paths, workers)
     out = torch.empty(len(decoded), 3, OUT, OUT, dtype=torch.float32, device=dev)
     groups = {}
     for i, a in enumerate(decoded):

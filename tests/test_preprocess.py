@@ -76,3 +76,19 @@ def test_image_files_mixed_sizes(tmp_path):
     dev = pp.load_and_transform_vision_data_device(paths).cpu()
     host = load_and_transform_vision_data(paths, "cpu")
     assert torch.equal(dev, host)
+
+
+def test_threaded_decode_keeps_order_and_pixels(tmp_path):
+    from PIL import Image
+    from hippomm_amd.preprocess import decode_rgb
+    rng = np.random.default_rng(0)
+    paths = []
+    for i in range(9):
+        a = rng.integers(0, 256, (40 + i, 60, 3), dtype=np.uint8)
+        p = tmp_path / f"f{i}.png"
+        Image.fromarray(a).save(p)
+        paths.append(str(p))
+    seq = decode_rgb(paths, workers=1)
+    par = decode_rgb(paths, workers=4)
+    assert [a.shape for a in seq] == [(40 + i, 60, 3) for i in range(9)]
+    assert all(np.array_equal(a, b) for a, b in zip(seq, par))
