@@ -10,6 +10,10 @@ checkpoint.  The reference has no tests or golden vectors for it.  What follows
 restates the published architecture (upstream files named per step) with
 ``torch.nn.functional`` fp32 CPU ops and keeps the upstream state-dict key
 names, so a real checkpoint can be loaded into it later to validate it.
+Independent cross-check (not a pin to the reference): tests/test_oracle_vs_hf_clip.py renames the weights of
+HuggingFace ``transformers``' CLIP vision / text models -- the same architecture family, written independently --
+to these keys and finds this file's ``vision_forward`` / ``text_forward`` equal to them to < 2e-5 on unit rows.
+The audio tower (add_bias_kv attention, stem LayerNorm, clip averaging) has no such counterpart here.
 
 Upstream structure restated here (imagebind/models/imagebind_model.py
 ``ImageBindModel`` with the ``imagebind_huge()`` overrides; transformer.py
