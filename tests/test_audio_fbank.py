@@ -70,6 +70,30 @@ def test_pure_tone_lands_in_the_predicted_band_with_the_predicted_energy():
     assert abs(top - ((mel_k0 - lo) / ((hi - lo) / 129) - 1)) <= 1.0   # centre of triangle `top` is nearest the tone
 
 
+@pytest.mark.parametrize("kind", ["noise", "tones"])
+def test_oracle_matches_transformers_audio_utils(kind):
+    """Independent implementation of the same definition: HuggingFace `transformers.audio_utils.spectrogram` with the
+    arguments its AST feature extractor uses when torchaudio is absent (kaldi-style: remove_dc_offset, preemphasis 0.97,
+    non-periodic Hann, 512-point power spectrum, kaldi mel scale triangularised in mel space, log with float32-eps floor),
+    evaluated in float64.  Not the reference's dependency, but written independently of this repository."""
+    au = pytest.importorskip("transformers.audio_utils")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                     # "at least one mel filter has all zero values": true, see above
+        mel_filters = au.mel_filter_bank(num_frequency_bins=257, num_mel_filters=128, min_frequency=20, max_frequency=8000,
+                                         sampling_rate=16000, norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+    ours = np.pad(fb.mel_banks().double().numpy(), ((0, 0), (0, 1))).T
+    assert np.abs(mel_filters - ours).max() < 5e-5           # float32 vs float64 arithmetic
+    w = _wave(2.0, kind)[0]
+    hf = au.spectrogram(w.double().numpy(), au.window_function(400, "hann", periodic=False), frame_length=400,
+                        hop_length=160, fft_length=512, power=2.0, center=False, preemphasis=0.97,
+                        mel_filters=mel_filters, log_mel="log", mel_floor=1.192092955078125e-07, remove_dc_offset=True).T
+    mine = fb.kaldi_fbank(w[None]).double().numpy()
+    assert hf.shape == mine.shape == (198, 128)
+    d = np.abs(hf - mine)
+    assert d.mean() < 3e-5 and d.max() < 5e-3                # the max sits in bands ~70 dB below the frame maximum
+
+
 def test_full_transform_shape_and_normalisation():
     w = torch.randn(1, 16000 * 7, generator=torch.Generator().manual_seed(0)) * 0.1
     out = fb.load_and_transform_audio(w)
