@@ -137,3 +137,23 @@ def test_text_tower_full_depth_and_query_flow():
     store = np.random.default_rng(0).standard_normal((50, 1024)).astype(np.float32)
     idx, sims = top_k_cosine_similarity(got[0], store, 5)                   # torch CUDA query, as at :3130-3134
     assert len(idx) == 5 and np.all(sims[:-1] >= sims[1:])
+
+
+def test_towers_match_committed_fixture():
+    """tests/golden/encoder_golden.json (the oracle's embeddings, committed): the HIP towers against the stored numbers,
+    weights regenerated from the recorded seeds."""
+    import importlib.util
+    import json
+    from pathlib import Path
+    from hippomm_amd.encoder import HipTower
+    gdir = Path(__file__).resolve().parent / "golden"
+    spec_ = importlib.util.spec_from_file_location("make_encoder_golden", gdir / "make_encoder_golden.py")
+    mk = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mk)
+    gold = json.loads((gdir / "encoder_golden.json").read_text())
+    scale = {"vision": 1.0, "audio": 20.0, "text": 1.0 / 0.07}
+    for name, spec, seed, x in mk.cases():
+        st = ib.synthetic_state(spec, seed=seed, init="rich")
+        assert mk.weights_sha(st) == gold[name]["weights_sha256"]
+        got = HipTower(name, st, depth=spec.depth)(x)
+        _check(got, torch.tensor(gold[name]["embeddings"]), scale=scale[name], what=f"{name} vs committed fixture")

@@ -74,3 +74,25 @@ def test_select_threshold_is_float32():
     assert float(np.float32(0.9)) < 0.9          # 0.89999998
     s = np.array([np.float32(0.9)], dtype=np.float32)
     assert not np.all(s < 0.9)
+
+
+# ---------------------------------------------------------------- encoder oracle regression fixture
+def test_encoder_oracle_regression_fixture():
+    """tests/golden/encoder_golden.json: the encoder oracle's own outputs on seeded weights / inputs (2-block towers).
+    Guards the unpinned oracle against drift (recipe, code or torch changes); it says nothing about the reference."""
+    import json
+    from pathlib import Path
+    import torch
+    sys_path = str(Path(__file__).resolve().parent / "golden")
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("make_encoder_golden", sys_path + "/make_encoder_golden.py")
+    mk = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mk)
+    gold = json.loads((Path(sys_path) / "encoder_golden.json").read_text())
+    for name, spec, seed, x in mk.cases():
+        st, y = mk.run(name, spec, seed, x)
+        case = gold[name]
+        assert mk.weights_sha(st) == case["weights_sha256"], f"{name}: the synthetic weight recipe changed"
+        want = torch.tensor(case["embeddings"], dtype=torch.float32)
+        assert y.shape == want.shape
+        assert (y - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), name
