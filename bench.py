@@ -186,6 +186,24 @@ def encoder_cpu_baseline():
                       f"pass after a 2-frame warm-up, torch intra-op threads = {threads}"}
 
 
+def torch_rocm_reference():
+    """The same ViT-H/14 tower through stock PyTorch-ROCm operators on this GPU (tools/torch_vit_probe.py): fp32 is what the
+    reference runs (ImageBind.forward under no_grad, no autocast, foundation_models.py:116-133), bf16 is the vendor-library
+    route.  A reported reference point, never part of the product path."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("torch_vit_probe_lib", os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                                  "tools", "torch_vit_lib.py"))
+    lib = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lib)
+    out = {}
+    for name, dtype, iters in (("fp32", torch.float32, 2), ("bf16", torch.bfloat16, 4)):
+        ms = lib.time_forward(FRAMES_PER_GPU, dtype, iters)
+        out[name] = {"ms_per_forward": round(ms, 2), "frames_per_s": round(FRAMES_PER_GPU / ms * 1e3, 1)}
+    out["what"] = ("stock PyTorch-ROCm operators (vendor GEMM, scaled_dot_product_attention, layer_norm, gelu), same batch, "
+                   "random weights; fp32 = the reference's own execution mode")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,6 +291,7 @@ def main():
                 line["scan"] = scan_bench(do_cpu=not args.no_cpu_baseline)
                 line["joint_vision_audio"] = joint_bench()
             if not args.no_cpu_baseline:
+                line["torch_rocm_reference"] = torch_rocm_reference()
                 line["cpu_baseline"] = encoder_cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
