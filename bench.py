@@ -127,6 +127,14 @@ def scan_bench(do_cpu):
     out["batched_16_queries"] = {"ms_per_pass": round(ms_multi, 4), "us_per_query": round(ms_multi / 16 * 1e3, 1),
                                  "store_read_GBps": round(algo_bytes / ms_multi / 1e6, 1),
                                  "speedup_vs_16_single_scans": round(16 * ms_query / ms_multi, 2)}
+    # reference point: the same query through stock PyTorch-ROCm operators on the resident store (vector_ops.py:151-188
+    # moved to the GPU as is: norms, matrix-vector product, division, top-k)
+    def torch_scan():
+        sims = (rows @ q) / (rows.norm(dim=1) * q.norm())
+        return torch.topk(sims, SCAN_K)
+    ms_torch = event_time_ms(torch_scan, 10, warmup=3)
+    out["torch_rocm_reference"] = {"ms_per_query": round(ms_torch, 4), "GBps": round(algo_bytes / ms_torch / 1e6, 1),
+                                   "what": "rows @ q / (rows.norm(dim=1) * q.norm()) + torch.topk on the same GPU"}
     if do_cpu:
         from oracle.vector_ops_oracle import top_k_cosine_similarity_oracle
         n_cpu = 200_000
