@@ -38,3 +38,15 @@ for mode, name in [(1, "full"), (0, "full, forward image order"), (9, "full, XCD
     t = timeit()
     print(f"{tower} n_img={n_img} {name:32s} {t:8.1f} us   {flops / t / 1e6:7.1f} TFLOP/s", flush=True)
 lib.hmm_dev_set_attn_reverse(9)
+
+# reference point: torch SDPA (vendor flash attention) on the same problem, q/k/v already split and head-major
+import torch.nn.functional as F
+q, k, v = (torch.randn(n_img, H, T, DH, device="cuda").bfloat16() * 0.5 for _ in range(3))
+for _ in range(3): F.scaled_dot_product_attention(q, k, v)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): F.scaled_dot_product_attention(q, k, v)
+e1.record(); torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / 20 * 1e3
+print(f"{tower} n_img={n_img} torch SDPA (contiguous head-major q/k/v, no packing/unpacking): {t:8.1f} us   {flops / t / 1e6:7.1f} TFLOP/s")
