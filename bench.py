@@ -105,10 +105,8 @@ def scan_bench(do_cpu):
     import ctypes as C
     from hippomm_amd import _lib as L
     lib = L.load()
-    lib.hmm_dev_scan_topk_only.restype = C.c_int
-    lib.hmm_dev_scan_topk_only.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     cand = torch.empty(2048 * SCAN_K, dtype=torch.int64, device="cuda")
-    ms_kernel = event_time_ms(lambda: L.check(lib.hmm_dev_scan_topk_only(rows.data_ptr(), SCAN_ROWS, q.data_ptr(), SCAN_K,
+    ms_kernel = event_time_ms(lambda: L.check(lib.hmm_op_scan_topk_only(rows.data_ptr(), SCAN_ROWS, q.data_ptr(), SCAN_K,
                                                                          cand.data_ptr(), L.stream_ptr()), "scan"), 20)
     algo_bytes = SCAN_ROWS * 4096.0
     out = {

@@ -45,14 +45,30 @@ _SIGNATURES = {
     "hmm_encoder_workspace_bytes": (C.c_size_t, [c_ptr, C.c_int]),
     "hmm_encoder_forward": (C.c_int, [c_ptr, c_ptr, C.c_int, c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "hmm_encoder_flops": (C.c_double, [c_ptr, C.c_int]),
+    "hmm_encoder_flops_executed": (C.c_double, [c_ptr, C.c_int]),
+    "hmm_encoder_set_streams": (C.c_int, [c_ptr, C.c_int]),
     "hmm_op_gemm_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     "hmm_op_layernorm_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr]),
+    "hmm_op_gemm_bf16_tile": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     "hmm_op_attention_bf16": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr]),
+    "hmm_op_attention_causal_bf16": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
+    "hmm_op_scan_topk_only": (C.c_int, [c_ptr, C.c_int64, c_ptr, C.c_int, c_ptr, c_ptr]),
+    "hmm_op_scan_sims": (C.c_int, [c_ptr, C.c_int64, c_ptr, c_ptr, c_ptr]),
 }
 
 
 class HippoMMHipError(RuntimeError):
     pass
+
+
+def bind(path):
+    """dlopen `path` and apply the binding table (also used by tools/ for the probe build of the same sources)."""
+    lib = C.CDLL(str(path))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI and the binding disagree
+        fn.restype = res
+        fn.argtypes = args
+    return lib
 
 
 def load():
@@ -64,13 +80,8 @@ def load():
         raise HippoMMHipError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -m hippomm_amd.build). "
             "hippomm_amd has no CPU fallback.")
-    lib = C.CDLL(str(LIB_PATH))
-    for name, (res, args) in _SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError if the ABI and the binding disagree
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = bind(LIB_PATH)
+    return _lib
 
 
 def check(status: int, what: str):

@@ -40,12 +40,11 @@ struct AttnCfg {
 };
 
 constexpr int kAttnWaves = 8;
-int g_attn_reverse = 9;   // tuning hook: 1 = walk images last-to-first, 8 = XCD-aware block order (see the kernel)
 
 template <int DH, int NKT>
 __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n_img, int T, int Lk, int H,
-    const float* __restrict__ bias_k, const float* __restrict__ bias_v, float scale_log2e, int reverse) {
+    const float* __restrict__ bias_k, const float* __restrict__ bias_v, float scale_log2e, int causal) {
     using C = AttnCfg<DH, NKT>;
     constexpr int NT = kAttnWaves * 64;
     constexpr int CPR = DH / 8;                      // 16-B chunks per K/V row
@@ -57,23 +56,16 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // walk the images backwards: the producer (QKV GEMM) wrote the last images last, so they are the
-    // ones still resident in the 256-MiB Infinity Cache when this kernel starts
     // XCD x = blockIdx % 8 takes the images x, x+8, ...: the 16 heads of an image then run on one XCD at about the same
-    // time, and a head's 160-B slice of a qkv row shares its 128-B lines with its neighbours' in that XCD's L2
-    int b_lin, h;
-    if (reverse & 8) {
-        const int n = blockIdx.x >> 3;
-        b_lin = (blockIdx.x & 7) + 8 * (n / H);
-        h = n % H;
-        if (b_lin >= n_img) return;
-    } else {
-        b_lin = blockIdx.x / H;
-        h = blockIdx.x % H;
-    }
-    const int b = (reverse & 1) ? n_img - 1 - b_lin : b_lin;
-    const bool abl_nocompute = reverse & 2, abl_noload = reverse & 4;   // timing ablations (wrong results)
-    const bool causal = reverse & 256;                                  // text tower: key j visible to query i iff j <= i
+    // time, and a head's 160-B slice of a qkv row shares its 128-B lines with its neighbours' in that XCD's L2.
+    // The images are walked backwards: the producer (QKV GEMM) wrote the last images last, so they are the
+    // ones still resident in the 256-MiB Infinity Cache when this kernel starts.
+    // causal (text tower): key j is visible to query i iff j <= i.
+    const int n = blockIdx.x >> 3;
+    const int b_lin = (blockIdx.x & 7) + 8 * (n / H);
+    const int h = n % H;
+    if (b_lin >= n_img) return;
+    const int b = n_img - 1 - b_lin;
     const int D = H * DH;
     const size_t row_stride = (size_t)3 * D;
     const bf16_t* base = qkv + (size_t)b * T * row_stride + h * DH;
@@ -102,11 +94,8 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
             const int row = idx / CPR, c = idx - row * CPR;
             const int rr = row < T ? row : T - 1;        // clamp: always a valid address; rows >= T are not written
             const bf16_t* p = base + (size_t)rr * row_stride + c * 8;
-            kv[i] = make_uint4(0u, 0u, 0u, 0u); vv[i] = kv[i];
-            if (!abl_noload) {
-                kv[i] = *reinterpret_cast<const uint4*>(p + D);
-                vv[i] = *reinterpret_cast<const uint4*>(p + 2 * D);
-            }
+            kv[i] = *reinterpret_cast<const uint4*>(p + D);
+            vv[i] = *reinterpret_cast<const uint4*>(p + 2 * D);
         }
         // rows T .. NKEY-1: zeros (the bias row, if any, is filled after the barrier)
         for (int idx = T * CPR + tid; idx < NCHUNK; idx += NT) {
@@ -143,7 +132,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
     // query, that query is instead processed cooperatively below: one key tile per wave.
     const bool coop = (nqt == kAttnWaves + 1) && (T - kAttnWaves * 32 == 1) && !causal;
     const int nqt_main = coop ? kAttnWaves : nqt;
-    for (int qt = wave; qt < (abl_nocompute ? 0 : nqt_main); qt += kAttnWaves) {
+    for (int qt = wave; qt < nqt_main; qt += kAttnWaves) {
         const int qrow = qt * 32 + r;
         if (qt != wave) {                                   // later tiles reload their queries
             const int qr = qrow < T ? qrow : T - 1;
@@ -277,7 +266,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
             }
     }
 
-    if (coop && !abl_nocompute) {
+    if (coop) {
         float* part = reinterpret_cast<float*>(smem + C::K_BYTES + C::V_BYTES);
         const int xq = T - 1;                                  // the extra query row
         const bf16_t* qp = base + (size_t)xq * row_stride + hh * 8;   // every column of the B operand = this query
@@ -362,16 +351,10 @@ static int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int T, in
                             const float* bias_k, const float* bias_v, hipStream_t st, bool causal) {
     using C = AttnCfg<DH, NKT>;
     auto kern = attention_kernel<DH, NKT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        attr_set = true;
-    }
+    HMM_ENSURE_DYN_LDS(kern, C::LDS);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
-    const int grid = (g_attn_reverse & 8) ? 8 * ((batch + 7) / 8) * H : batch * H;
-    kern<<<grid, kAttnWaves * 64, C::LDS, st>>>(qkv, out, batch, T, Lk, H, bias_k, bias_v, scale_log2e,
-                                                g_attn_reverse | (causal ? 256 : 0));
+    const int grid = 8 * ((batch + 7) / 8) * H;
+    kern<<<grid, kAttnWaves * 64, C::LDS, st>>>(qkv, out, batch, T, Lk, H, bias_k, bias_v, scale_log2e, causal ? 1 : 0);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
@@ -509,10 +492,7 @@ extern "C" int hmm_op_attention_bf16(const uint16_t* qkv_dev, uint16_t* out_dev,
                           heads, head_dim, bias_k_dev, bias_v_dev, static_cast<hipStream_t>(stream));
 }
 
-extern "C" void hmm_dev_set_attn_reverse(int v) { hmm::g_attn_reverse = v; }
-
-// causal variant of hmm_op_attention_bf16 (text tower); testing hook
-extern "C" int hmm_dev_attention_causal_bf16(const uint16_t* qkv_dev, uint16_t* out_dev, int batch, int tokens, int heads,
+extern "C" int hmm_op_attention_causal_bf16(const uint16_t* qkv_dev, uint16_t* out_dev, int batch, int tokens, int heads,
                                              int head_dim, hmm_stream_t stream) {
     return attention_bf16(reinterpret_cast<const bf16_t*>(qkv_dev), reinterpret_cast<bf16_t*>(out_dev), batch, tokens,
                           heads, head_dim, nullptr, nullptr, static_cast<hipStream_t>(stream), true);

@@ -555,8 +555,8 @@ extern "C" int hmm_topk_merge_keys(const uint64_t* keys_dev, int n_shards, int k
     return HMM_OK;
 }
 
-// Timing hook (not in the public header): the streaming kernel alone, for bench.py's roofline.
-extern "C" int hmm_dev_scan_sims(const float* store_dev, int64_t n_rows, const float* query_dev, float* sims_dev,
+// Timing / test hook (include/hippomm_hip.h): the plain similarity pass alone.
+extern "C" int hmm_op_scan_sims(const float* store_dev, int64_t n_rows, const float* query_dev, float* sims_dev,
                                  hmm_stream_t stream) {
     int64_t waves_needed = (n_rows + 1) / 2;
     int blocks = (int)((waves_needed + 3) / 4);
@@ -568,7 +568,7 @@ extern "C" int hmm_dev_scan_sims(const float* store_dev, int64_t n_rows, const f
 }
 
 // Timing hook: the fused streaming + block-top-k kernel alone (the dominant kernel of a query).
-extern "C" int hmm_dev_scan_topk_only(const float* store_dev, int64_t n_rows, const float* query_dev, int k,
+extern "C" int hmm_op_scan_topk_only(const float* store_dev, int64_t n_rows, const float* query_dev, int k,
                                       uint64_t* cand_dev /* [2048*k] */, hmm_stream_t stream) {
     HMM_REQUIRE(k >= 1 && k <= kFusedK, HMM_E_INVALID, "scan_topk_only: k out of range");
     int64_t waves_needed = (n_rows + 1) / 2;

@@ -281,8 +281,6 @@ __global__ __launch_bounds__(1024) void topk_final_multi_kernel(const uint64_t* 
     }
 }
 
-int g_multi_rotate = 1;     // tuning hook
-
 static int multi_grid(int64_t n_rows) {
     const int64_t chunks = (n_rows + kMRows - 1) / kMRows;
     return (int)(chunks < 2 * kNumCU ? chunks : 2 * kNumCU);
@@ -328,18 +326,13 @@ extern "C" int hmm_cosine_topk_multi(const float* store_dev, int64_t n_rows, int
         }
         return HMM_OK;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        HMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_multi_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MultiLds)));
-        attr_set = true;
-    }
+    HMM_ENSURE_DYN_LDS(scan_multi_kernel, (int)sizeof(MultiLds));
     const int grid = multi_grid(n_rows);
     uint64_t* cand = static_cast<uint64_t*>(workspace_dev);
     for (int q0 = 0; q0 < n_queries; q0 += kMQ) {                  // 16 queries per pass over the store
         const int nq = n_queries - q0 < kMQ ? n_queries - q0 : kMQ;
         scan_multi_kernel<<<grid, kMWaves * 64, sizeof(MultiLds), st>>>(store_dev, n_rows, queries_dev + (size_t)q0 * dim,
-                                                                       nq, k_eff, cand, g_multi_rotate);
+                                                                       nq, k_eff, cand, 1);
         HMM_LAUNCH_CHECK();
         topk_final_multi_kernel<<<nq, 1024, 0, st>>>(cand, grid, k_eff, k_eff, idx_out_dev + (size_t)q0 * k,
                                                      sim_out_dev + (size_t)q0 * k, n_out_dev ? n_out_dev + q0 : nullptr, k);
@@ -347,5 +340,3 @@ extern "C" int hmm_cosine_topk_multi(const float* store_dev, int64_t n_rows, int
     }
     return HMM_OK;
 }
-
-extern "C" void hmm_dev_set_multi_rotate(int v) { hmm::g_multi_rotate = v; }

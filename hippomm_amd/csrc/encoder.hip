@@ -46,6 +46,8 @@ struct hmm_encoder {
     int tower, D, depth, heads, mlp, n_patches, T, patch_k, patch_k_pad, clips;
     bool pre_ln, stem_ln, bias_kv, scaled;
     bool ready = false;
+    int device = 0;                         // the device the handle was created on (weights, side stream, events)
+    int streams = 2;                        // 2: half-batches on two streams (default), 1: one chain (hmm_encoder_set_streams)
     hipStream_t side_stream = nullptr;      // second half-batch runs here (see hmm_encoder_forward)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     char* arena = nullptr;
@@ -198,10 +200,17 @@ extern "C" int hmm_encoder_create(hmm_encoder** out, int tower, int depth) {
     e->patch_w = e->head_w = nullptr;
     std::vector<std::pair<void**, size_t>> fix;
     plan_params(e, fix);
-    hipError_t err = hipMalloc(reinterpret_cast<void**>(&e->arena), e->arena_bytes);
+    hipError_t err = hipGetDevice(&e->device);
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->arena), e->arena_bytes);
+    // the side stream and its fork/join events belong to the handle's device and exist before the first forward,
+    // so that hmm_encoder_forward creates nothing (graph capture) and never lands them on another current device
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
     if (err != hipSuccess) {
-        set_error("encoder_create: hipMalloc(%zu) failed: %s", e->arena_bytes, hipGetErrorString(err));
-        delete e;
+        set_error("encoder_create: device allocation (%zu B arena, side stream) failed: %s", e->arena_bytes,
+                  hipGetErrorString(err));
+        hmm_encoder_destroy(e);
         return HMM_E_HIP;
     }
     for (auto& f : fix) *f.first = e->arena + f.second;
@@ -252,14 +261,12 @@ extern "C" int hmm_encoder_missing_params(hmm_encoder* e) {
 }
 
 namespace hmm {
-int g_encoder_streams = 2;   // tuning hook: 1 = single chain, 2 = two half-batches on two streams
-
 // Two half-batches on two streams: the HBM-bound kernels of one half (LayerNorm, K/V staging of the
 // attention, residual read-modify-write epilogues) overlap the MFMA-bound GEMM tiles of the other on
 // different CUs.  Measured -4.5 % on the ViT-H forward at batch 256; per-frame results are unchanged
 // (every frame's rows go through the same kernels with the same K order).
 static int split_point(const hmm_encoder* e, int batch) {
-    if (g_encoder_streams < 2 || batch * e->clips < 64) return 0;
+    if (e->streams < 2 || batch * e->clips < 64) return 0;
     return batch / 2;
 }
 }  // namespace hmm
@@ -279,6 +286,19 @@ extern "C" double hmm_encoder_flops(const hmm_encoder* e, int batch) {
     double macs = e->n_patches * patch_k * D;                        // patch projection
     macs += e->depth * (T * D * (3 * D + D + 2 * H) + 2 * T * Lk * D);   // projections + MLP + QK^T + PV
     macs += D * HMM_FEATURE_DIM;                                     // head
+    return 2.0 * macs * batch * e->clips;
+}
+
+extern "C" double hmm_encoder_flops_executed(const hmm_encoder* e, int batch) {
+    if (!e || batch < 1) return 0.0;
+    const double D = e->D, T = e->T, H = e->mlp, Lk = e->T + (e->bias_kv ? 1 : 0);
+    const bool text = e->tower == HMM_TOWER_TEXT;
+    double macs = text ? 0.0 : (double)e->n_patches * e->patch_k_pad * D;          // folded, K-padded patch projection
+    const double full = T * D * (3 * D + D + 2 * H) + 2 * T * Lk * D;               // one whole block
+    // last block of the vision / audio towers: K|V projection of every token, everything else for token 0 only
+    const double last = T * D * 2 * D + D * (D + D + 2 * H) + 2 * Lk * D;
+    macs += text ? e->depth * full : (e->depth - 1) * full + last;
+    macs += D * HMM_FEATURE_DIM;                                                    // head
     return 2.0 * macs * batch * e->clips;
 }
 
@@ -370,6 +390,10 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
                                    void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream) {
     HMM_REQUIRE(e && input_dev && out_dev && workspace_dev, HMM_E_INVALID, "encoder_forward: null argument");
     HMM_REQUIRE(batch >= 1, HMM_E_INVALID, "encoder_forward: batch=%d", batch);
+    int cur_dev = -1;
+    HMM_HIP_CHECK(hipGetDevice(&cur_dev));
+    HMM_REQUIRE(cur_dev == e->device, HMM_E_STATE, "encoder_forward: handle lives on device %d, current device is %d",
+                e->device, cur_dev);
     if (!e->ready) {
         HMM_REQUIRE(hmm_encoder_missing_params(e) == 0, HMM_E_STATE, "encoder_forward: %s", hmm_last_error());
         e->ready = true;
@@ -389,11 +413,6 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
     if (b0 == 0) {
         chains[0] = Chain{input_dev, out_dev, ws, ws_plan(e, batch), st, batch};
     } else {
-        if (!e->side_stream) {
-            HMM_HIP_CHECK(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
-            HMM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-            HMM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-        }
         const WsPlan p0 = ws_plan(e, b0);
         chains[0] = Chain{input_dev, out_dev, ws, p0, st, b0};
         chains[1] = Chain{static_cast<const char*>(input_dev) + (size_t)b0 * in_bytes_per_sample, out_dev + (size_t)b0 * HMM_FEATURE_DIM,
@@ -402,20 +421,31 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
         HMM_HIP_CHECK(hipEventRecord(e->ev_fork, st));                       // fork
         HMM_HIP_CHECK(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
     }
-    int rc;
     // launches are interleaved block by block so that both streams always have work queued
-    for (int c = 0; c < n_chains; ++c)
-        if ((rc = chain_tokens(e, chains[c])) != HMM_OK) return rc;
-    for (int i = 0; i < e->depth; ++i)
-        for (int c = 0; c < n_chains; ++c)
-            if ((rc = chain_block(e, chains[c], i)) != HMM_OK) return rc;
-    for (int c = 0; c < n_chains; ++c)
-        if ((rc = chain_head(e, chains[c])) != HMM_OK) return rc;
+    int rc = HMM_OK;
+    for (int c = 0; c < n_chains && rc == HMM_OK; ++c) rc = chain_tokens(e, chains[c]);
+    for (int i = 0; i < e->depth && rc == HMM_OK; ++i)
+        for (int c = 0; c < n_chains && rc == HMM_OK; ++c) rc = chain_block(e, chains[c], i);
+    for (int c = 0; c < n_chains && rc == HMM_OK; ++c) rc = chain_head(e, chains[c]);
     if (n_chains == 2) {
-        HMM_HIP_CHECK(hipEventRecord(e->ev_join, e->side_stream));           // join
-        HMM_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));
+        // join -- also when a launch failed mid-chain: whatever was queued on the side stream must be ordered before
+        // the caller's stream continues (the caller may free or reuse the workspace right after an error return)
+        const hipError_t j0 = hipEventRecord(e->ev_join, e->side_stream);
+        const hipError_t j1 = j0 == hipSuccess ? hipStreamWaitEvent(st, e->ev_join, 0) : j0;
+        if (j1 != hipSuccess) {
+            (void)hipStreamSynchronize(e->side_stream);                      // last resort: block the host instead
+            if (rc == HMM_OK) {
+                set_error("encoder_forward: joining the side stream failed: %s", hipGetErrorString(j1));
+                rc = HMM_E_HIP;
+            }
+        }
     }
-    return HMM_OK;
+    return rc;
 }
 
-extern "C" void hmm_dev_set_encoder_streams(int n) { hmm::g_encoder_streams = n; }
+extern "C" int hmm_encoder_set_streams(hmm_encoder* e, int n_streams) {
+    HMM_REQUIRE(e, HMM_E_INVALID, "encoder_set_streams: null handle");
+    HMM_REQUIRE(n_streams == 1 || n_streams == 2, HMM_E_INVALID, "encoder_set_streams: %d (1 or 2)", n_streams);
+    e->streams = n_streams;
+    return HMM_OK;
+}

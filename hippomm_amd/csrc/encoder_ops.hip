@@ -249,15 +249,12 @@ __global__ void fold_conv3d_kernel(const float* __restrict__ w, bf16_t* __restri
     dst[i] = (bf16_t)v;
 }
 
-int g_ln_max_blocks = 0;   // tuning hook: > 0 caps the LayerNorm grid (persistent, grid-stride)
-
 // ---- launchers ------------------------------------------------------------------------------
 int launch_layernorm_bf16(const float* x, size_t in_stride, const float* g, const float* b, bf16_t* y,
                           int rows, int D, float eps, hipStream_t st) {
     HMM_REQUIRE(D == 768 || D == 1024 || D == 1280, HMM_E_INVALID, "layernorm: D must be 768, 1024 or 1280, got %d", D);
     if (rows <= 0) return HMM_OK;
     int blocks = (rows + 3) / 4;
-    if (g_ln_max_blocks > 0 && blocks > g_ln_max_blocks) blocks = g_ln_max_blocks;
     if (D == 768)       layernorm_bf16_kernel<3><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps);
     else if (D == 1024) layernorm_bf16_kernel<4><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps);
     else                layernorm_bf16_kernel<5><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps);
@@ -347,5 +344,3 @@ extern "C" int hmm_op_layernorm_bf16(const float* x_dev, const float* gamma_dev,
     return launch_layernorm_bf16(x_dev, (size_t)D, gamma_dev, beta_dev, reinterpret_cast<bf16_t*>(y_dev), rows, D, eps,
                                  static_cast<hipStream_t>(stream));
 }
-
-extern "C" void hmm_dev_set_ln_max_blocks(int n) { hmm::g_ln_max_blocks = n; }

@@ -308,25 +308,25 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
 // Hazards: a half-tile is re-staged only in a phase after the one whose reads were retired by
 // lgkmcnt(0) *before* that phase's first barrier (WAR); staged data is read only in a phase after
 // the barrier that follows every wave's counted vmcnt (RAW).
+// Tiles are walked in plain strips (whole row tiles, XCD-contiguous); ablations, tile-walk and pipeline variants that
+// were measured and rejected are recorded in DESIGN.md section 4.3 / 4.5, not kept in the code.
 // ------------------------------------------------------------------------------------------------
-template <int EPI, int F = 0>
+#ifdef HMM_PROBE
+// probe build: first-round workgroups of slot group ((blockIdx/8) % groups) start `units` x ~1 us x group late, so that
+// the CUs of one XCD do not run their epilogue store bursts at the same instant
+HMM_TUNABLE(int, g_gemm_dephase_units, 0)
+HMM_TUNABLE(int, g_gemm_dephase_groups, 4)
+#define HMM_PROBE_ARG , int dephase
+#define HMM_PROBE_VAL , (g_gemm_dephase_groups << 16) | g_gemm_dephase_units
+#else
+#define HMM_PROBE_ARG
+#define HMM_PROBE_VAL
+#endif
+
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    void* __restrict__ Cout, int M, int N, int K, int tiles_n, int g_tile_group_n) {
-    // F: experiment flags (0 in production).  1: P1 waits only for its kh=0 fragments before the
-    // barrier; 2: no s_setprio; 4: no stagger between the wave groups; 8: ablation, no in-loop DMA;
-    // 16: ablation, no in-loop LDS reads (8 and 16 give wrong results; timing only).
-    constexpr bool F_PARTIAL = F & 1, F_NOPRIO = F & 2, F_NOSTAG = F & 4, F_NODMA = F & 8, F_NOLDS = F & 16;
-    constexpr bool F_NOEPI = F & 32;   // ablation: keep only one store per wave (results wrong)
-    constexpr bool F_DEPHASE = F & 64; // first-round blocks start (blockIdx%8) x ~1.5 us apart
-    constexpr bool F_EARLY = !(F & 512);     // default: stage (t+2).A_hi in P4(t) (with B_hi) instead of (t+1).A_hi in P1(t):
-                                             // every half-tile then has >= 4 phases of lead before the counted wait (+1-2 %)
-    // residual epilogue: touch the tile's fp32 residual lines with 4-byte LDS-DMA loads during K-tiles 0..3 so that
-    // the epilogue's read-modify-write finds them in L2 / Infinity Cache instead of bursting HBM reads with its writes
-    // (opt-in experiment, measured NEGATIVE: out-proj 282 -> 320 us -- 64 scattered line requests per touch)
-    constexpr bool F_XPF = (EPI == HMM_EPI_BIAS_RESID_F32) && F_EARLY && (F & 1024);
-    constexpr bool F_BAL = (F & 256) != 0; // opt-in: P4 prefetches the next K-tile's A_lo kh=0 fragments (LDS-read
-                                           // balancing; measured null, +20 VGPRs)
+    void* __restrict__ Cout, int M, int N, int K, int tiles_n HMM_PROBE_ARG) {
     constexpr int HALF = 16384, TILE = 4 * HALF;
     constexpr int H_ALO = 0, H_AHI = HALF, H_BLO = 2 * HALF, H_BHI = 3 * HALF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -338,21 +338,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const int nb = gridDim.x, bid = blockIdx.x;
     const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    // Tile walk inside the XCD's range: column groups of gn tiles, row-major inside a group (gn = tiles_n: plain strips
-    // of whole row tiles, the default).  PMC shows the strip order pulling all of W through the fabric once per row tile
-    // (3.4 GB per fc1 GEMM for 0.85 GB of algorithmic traffic), and with gn = 4 an isolated qkv GEMM runs at 1214 instead
-    // of 995 TFLOP/s -- but inside the tower, where the activations were just written by the previous kernel and sit in
-    // the Infinity Cache, the grouped walk re-reads them tiles_n / gn times and writes 2-KiB row pieces: every GEMM is
-    // 3-7 % SLOWER in situ (rocprof, same process: qkv 520 -> 558 us, fc1 811 -> 832 us; forward 90.6 -> 93.7 ms).
-    const int gn = g_tile_group_n > 0 && g_tile_group_n < tiles_n ? g_tile_group_n : tiles_n;
-    const int tiles_m = nb / tiles_n, per_group = gn * tiles_m;
-    const int grp = swz / per_group, rem = swz - grp * per_group;
-    const int first = grp * gn, width = tiles_n - first < gn ? tiles_n - first : gn;      // the last group may be narrower
-    const int m0 = (rem / width) * 256, n0 = (first + rem % width) * 256;
-    if constexpr (F_DEPHASE) {
-        if (bid < 2 * kNumCU)
-            for (int i = 0; i < xcd; ++i) __builtin_amdgcn_s_sleep(47);
+    const int m0 = (swz / tiles_n) * 256, n0 = (swz % tiles_n) * 256;
+#ifdef HMM_PROBE
+    if ((dephase & 0xFFFF) && bid < kNumCU) {
+        const int grp = (bid >> 3) % (dephase >> 16);
+        for (int i = 0; i < grp * (dephase & 0xFFFF); ++i) __builtin_amdgcn_s_sleep(32);
     }
+#endif
 
     // staging sources as 32-bit element offsets from A / W (launcher guarantees M*K, N*K < 2^31):
     // half-tile local row lr = (wave + 8j)*8 + (lane>>3), 16-B chunk (lane&7) un-swizzled
@@ -371,18 +363,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
         src_blo[j] = (n0 + bcol) * K + c * 8;
         src_bhi[j] = (n0 + bcol + 32) * K + c * 8;
     }
-#define HMM_STAGE2(base, src, kt, buf, half)                                                                \
+#define HMM_STAGE(base, src, kt, buf, half)                                                                 \
     do {                                                                                                    \
         __builtin_amdgcn_global_load_lds(HMM_GLB_PTR((base) + (ptrdiff_t)(src[0] + (kt) * 64)),             \
                                          HMM_LDS_PTR(smem + (buf) * TILE + (half) + wave * 1024), 16, 0, 0); \
         __builtin_amdgcn_global_load_lds(HMM_GLB_PTR((base) + (ptrdiff_t)(src[1] + (kt) * 64)),             \
                                          HMM_LDS_PTR(smem + (buf) * TILE + (half) + (wave + 8) * 1024), 16, 0, 0); \
     } while (0)
-#define HMM_STAGE(src, kt, buf, half) HMM_STAGE_##src(kt, buf, half)
-#define HMM_STAGE_src_alo(kt, buf, half) HMM_STAGE2(A, src_alo, kt, buf, half)
-#define HMM_STAGE_src_ahi(kt, buf, half) HMM_STAGE2(A, src_ahi, kt, buf, half)
-#define HMM_STAGE_src_blo(kt, buf, half) HMM_STAGE2(W, src_blo, kt, buf, half)
-#define HMM_STAGE_src_bhi(kt, buf, half) HMM_STAGE2(W, src_bhi, kt, buf, half)
 
     // fragment read bases (bytes inside a half-tile)
     const int fsw = (lane & 15) >> 1;
@@ -396,52 +383,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[4][2], blo[2][2], bhi[2][2];
-    // residual-prefetch addresses: the 256x256 fp32 tile is 2048 lines of 128 B; thread tid touches lines tid + 512*i
-    const float* xpf_base = static_cast<const float*>(Cout);
-    int xpf_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int line = (int)threadIdx.x + 512 * i;
-        int row = m0 + (line >> 3);
-        row = row < M ? row : M - 1;
-        xpf_off[i] = F_XPF ? row * N + n0 + (line & 7) * 32 : 0;
-    }
-    bf16x8 apre[4];                                           // next K-tile's A_lo, kh = 0 (read in P4)
 
-#define HMM_READ_A_KH(buf, half, kh, ck)                                                              \
-    if (!F_NOLDS || t_first) {                                                                        \
+#define HMM_READ_A(buf, half)                                                                         \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                  \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
-        af[mi][kh] = *reinterpret_cast<const bf16x8*>(a_rd + (buf) * TILE + (half) + mi * 2048 + ck); }
-#define HMM_READ_B_KH(dst, buf, half, kh, ck)                                                         \
-    if (!F_NOLDS || t_first) {                                                                        \
+        af[mi][kh] = *reinterpret_cast<const bf16x8*>(a_rd + (buf) * TILE + (half) + mi * 2048 + (kh ? ck1 : ck0));
+#define HMM_READ_B(dst, buf, half)                                                                    \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                  \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
-        dst[ni][kh] = *reinterpret_cast<const bf16x8*>(b_rd + (buf) * TILE + (half) + ni * 2048 + ck); }
-#define HMM_READ_A(buf, half) HMM_READ_A_KH(buf, half, 0, ck0) HMM_READ_A_KH(buf, half, 1, ck1)
-#define HMM_READ_B(dst, buf, half) HMM_READ_B_KH(dst, buf, half, 0, ck0) HMM_READ_B_KH(dst, buf, half, 1, ck1)
-#define HMM_MFMA_HALF(mo, no, bsrc, kh)                                                               \
+        dst[ni][kh] = *reinterpret_cast<const bf16x8*>(b_rd + (buf) * TILE + (half) + ni * 2048 + (kh ? ck1 : ck0));
+#define HMM_MFMA_QUAD(mo, no, bsrc)                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                  \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
         acc[(mo) + mi][(no) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[ni][kh], af[mi][kh], \
-                                                                            acc[(mo) + mi][(no) + ni], 0, 0, 0);
-#define HMM_MFMA_HALF_PRE(mo, no, bsrc)    /* kh = 0 with the prefetched A_lo fragments */             \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
-        acc[(mo) + mi][(no) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[ni][0], apre[mi],    \
-                                                                            acc[(mo) + mi][(no) + ni], 0, 0, 0);
-#define HMM_MFMA_QUAD_PRE(mo, no, bsrc)                                                               \
-    if constexpr (!F_NOPRIO) __builtin_amdgcn_s_setprio(1);                                           \
-    HMM_MFMA_HALF_PRE(mo, no, bsrc) HMM_MFMA_HALF(mo, no, bsrc, 1)                                     \
-    if constexpr (!F_NOPRIO) __builtin_amdgcn_s_setprio(0);
-#define HMM_MFMA_QUAD(mo, no, bsrc)                                                                   \
-    if constexpr (!F_NOPRIO) __builtin_amdgcn_s_setprio(1);                                           \
-    HMM_MFMA_HALF(mo, no, bsrc, 0) HMM_MFMA_HALF(mo, no, bsrc, 1)                                      \
-    if constexpr (!F_NOPRIO) __builtin_amdgcn_s_setprio(0);
-#define HMM_MFMA_QUAD_SPLIT(mo, no, bsrc)                                                             \
-    if constexpr (!F_NOPRIO) __builtin_amdgcn_s_setprio(1);                                           \
-    HMM_MFMA_HALF(mo, no, bsrc, 0)                                                                    \
-    __builtin_amdgcn_sched_barrier(0); HMM_LGKM0(); __builtin_amdgcn_sched_barrier(0);                \
-    HMM_MFMA_HALF(mo, no, bsrc, 1)                                                                    \
-    if constexpr (!F_NOPRIO) __builtin_amdgcn_s_setprio(0);
+                                                                            acc[(mo) + mi][(no) + ni], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
 #define HMM_BAR()                              \
     __builtin_amdgcn_sched_barrier(0);         \
     __builtin_amdgcn_s_barrier();              \
@@ -449,82 +407,36 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 #define HMM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
     const int KT = K >> 6;                                    // even, >= 2 (checked by the launcher)
-    // prologue: K-tile 0 complete, K-tile 1 minus A_hi (which P1 of tile 0 stages)
-    HMM_STAGE(src_alo, 0, 0, H_ALO); HMM_STAGE(src_blo, 0, 0, H_BLO);
-    HMM_STAGE(src_bhi, 0, 0, H_BHI); HMM_STAGE(src_ahi, 0, 0, H_AHI);
-    HMM_STAGE(src_alo, 1, 1, H_ALO); HMM_STAGE(src_blo, 1, 1, H_BLO); HMM_STAGE(src_bhi, 1, 1, H_BHI);
-    if constexpr (F_EARLY) {
-        HMM_STAGE(src_ahi, 1, 1, H_AHI);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    }
+    // prologue: K-tiles 0 and 1 complete; wait for tile 0 only
+    HMM_STAGE(A, src_alo, 0, 0, H_ALO); HMM_STAGE(W, src_blo, 0, 0, H_BLO);
+    HMM_STAGE(W, src_bhi, 0, 0, H_BHI); HMM_STAGE(A, src_ahi, 0, 0, H_AHI);
+    HMM_STAGE(A, src_alo, 1, 1, H_ALO); HMM_STAGE(W, src_blo, 1, 1, H_BLO);
+    HMM_STAGE(W, src_bhi, 1, 1, H_BHI); HMM_STAGE(A, src_ahi, 1, 1, H_AHI);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     HMM_BAR();
-    if (!F_NOSTAG && wm == 1) { HMM_BAR(); }                  // waves 4-7 run one barrier behind
+    if (wm == 1) { HMM_BAR(); }                               // waves 4-7 run one barrier behind
 
 #define HMM_KTILE(t, buf)                                                                 \
     {                                                                                     \
         /* P1: quadrant (lo,lo) */                                                        \
-        const bool t_first = (t) < 2;                                                     \
-        if constexpr (F_PARTIAL) {                                                        \
-            HMM_READ_A_KH(buf, H_ALO, 0, ck0) HMM_READ_B_KH(blo, buf, H_BLO, 0, ck0)      \
-            HMM_READ_A_KH(buf, H_ALO, 1, ck1) HMM_READ_B_KH(blo, buf, H_BLO, 1, ck1)      \
-            if (!F_EARLY && !F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");                            \
-            HMM_BAR() HMM_MFMA_QUAD_SPLIT(0, 0, blo) HMM_BAR()                            \
-        } else if constexpr (F_BAL) {                                                     \
-            if ((t) == 0) {                                                               \
-                _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                          \
-                    apre[mi] = *reinterpret_cast<const bf16x8*>(a_rd + (buf) * TILE + H_ALO + mi * 2048 + ck0); \
-            }                                                                             \
-            HMM_READ_A_KH(buf, H_ALO, 1, ck1) HMM_READ_B(blo, buf, H_BLO)                 \
-            if (!F_EARLY && !F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
-            HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD_PRE(0, 0, blo) HMM_BAR()                 \
-        } else {                                                                          \
-            HMM_READ_A(buf, H_ALO) HMM_READ_B(blo, buf, H_BLO)                            \
-            if (!F_EARLY && !F_NODMA && (t) + 1 < KT) HMM_STAGE(src_ahi, (t) + 1, (buf) ^ 1, H_AHI);  \
-            HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(0, 0, blo) HMM_BAR()                     \
-        }                                                                                 \
+        HMM_READ_A(buf, H_ALO) HMM_READ_B(blo, buf, H_BLO)                                \
+        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(0, 0, blo) HMM_BAR()                         \
         /* P2: (lo,hi) */                                                                 \
         HMM_READ_B(bhi, buf, H_BHI)                                                       \
-        if (!F_NODMA && (t) + 2 < KT) HMM_STAGE(src_alo, (t) + 2, buf, H_ALO);            \
-        HMM_LGKM0(); HMM_BAR()                                                            \
-        if constexpr (F_BAL) { HMM_MFMA_QUAD_PRE(0, 2, bhi) } else { HMM_MFMA_QUAD(0, 2, bhi) } \
-        HMM_BAR()                                                                         \
+        if ((t) + 2 < KT) HMM_STAGE(A, src_alo, (t) + 2, buf, H_ALO);                     \
+        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(0, 2, bhi) HMM_BAR()                         \
         /* P3: (hi,hi) */                                                                 \
         HMM_READ_A(buf, H_AHI)                                                            \
-        if (!F_NODMA && (t) + 2 < KT) HMM_STAGE(src_blo, (t) + 2, buf, H_BLO);            \
-        if constexpr (F_BAL) {                                                            \
-            /* (t+1).A_lo was staged 5 phases ago; younger: (t+1).B_lo, B_hi, A_hi, (t+2).A_lo, B_lo */ \
-            if ((t) + 2 < KT) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");           \
-            else if ((t) + 1 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       \
-        }                                                                                 \
+        if ((t) + 2 < KT) HMM_STAGE(W, src_blo, (t) + 2, buf, H_BLO);                     \
         HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(4, 2, bhi) HMM_BAR()                         \
-        /* P4: (hi,lo) */                                                                 \
-        if constexpr (F_BAL) {                                                            \
-            if ((t) + 1 < KT) {                                                           \
-                _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                          \
-                    apre[mi] = *reinterpret_cast<const bf16x8*>(a_rd + ((buf) ^ 1) * TILE + H_ALO + mi * 2048 + ck0); \
-            }                                                                             \
-        }                                                                                 \
-        if (!F_NODMA && (t) + 2 < KT) {                                                   \
-            HMM_STAGE(src_bhi, (t) + 2, buf, H_BHI);                                      \
-            if constexpr (F_EARLY) {                                                      \
-                HMM_STAGE(src_ahi, (t) + 2, buf, H_AHI);                                  \
-                if (F_XPF && (t) < 4) {                                                   \
-                    __builtin_amdgcn_global_load_lds(HMM_GLB_PTR(xpf_base + (size_t)xpf_off[(t) & 3]), \
-                                                     HMM_LDS_PTR(smem + 8 * kEpiSlab + wave * 256), 4, 0, 0); \
-                    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                      \
-                } else {                                                                  \
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                      \
-                }                                                                         \
-            } else {                                                                      \
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                          \
-            }                                                                             \
+        /* P4: (hi,lo); retire K-tile t+1, leave the four half-tiles of t+2 in flight */  \
+        if ((t) + 2 < KT) {                                                               \
+            HMM_STAGE(W, src_bhi, (t) + 2, buf, H_BHI);                                   \
+            HMM_STAGE(A, src_ahi, (t) + 2, buf, H_AHI);                                   \
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                              \
         } else {                                                                          \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              \
         }                                                                                 \
-        if constexpr (F_BAL) { HMM_LGKM0(); }                                             \
         HMM_BAR() HMM_MFMA_QUAD(4, 0, blo) HMM_BAR()                                      \
     }
 
@@ -532,61 +444,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
         HMM_KTILE(t, 0)
         HMM_KTILE(t + 1, 1)
     }
-    if (!F_NOSTAG && wm == 0) { HMM_BAR(); }                  // re-align the two wave groups
+    if (wm == 0) { HMM_BAR(); }                               // re-align the two wave groups
 #undef HMM_KTILE
 #undef HMM_STAGE
-#undef HMM_STAGE2
-#undef HMM_STAGE_src_alo
-#undef HMM_STAGE_src_ahi
-#undef HMM_STAGE_src_blo
-#undef HMM_STAGE_src_bhi
 #undef HMM_READ_A
 #undef HMM_READ_B
 #undef HMM_MFMA_QUAD
-#undef HMM_MFMA_QUAD_SPLIT
-#undef HMM_MFMA_QUAD_PRE
-#undef HMM_MFMA_HALF_PRE
-#undef HMM_MFMA_HALF
-#undef HMM_READ_A_KH
-#undef HMM_READ_B_KH
 
-    if constexpr (F_NOEPI) {
-        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) sum += acc[mi][ni];
-        const int m = m0 + wm * 128 + (lane & 15), n = n0 + wn * 64 + 4 * (lane >> 4);
-        if (m < M) {
-            bf16x4 o4 = {(bf16_t)sum[0], (bf16_t)sum[1], (bf16_t)sum[2], (bf16_t)sum[3]};
-            *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(Cout) + (size_t)m * N + n) = o4;
-        }
-    } else if constexpr (F & 128) {
-        gemm_epilogue<EPI, 8, 4>(acc, bias, Cout, M, N, m0 + wm * 128 + (lane & 15), n0 + wn * 64 + 4 * (lane >> 4));
-    } else {
-        // every wave is past its last LDS read and every DMA has landed: the LDS is free
-        if constexpr (F_NOSTAG) { HMM_BAR(); }
-        gemm_epilogue_lds<EPI>(acc, bias, Cout, M, N, m0 + wm * 128, n0 + wn * 64, smem + wave * kEpiSlab, lane);
-    }
+    // every wave is past its last LDS read and every DMA has landed: the LDS is free
+    gemm_epilogue_lds<EPI>(acc, bias, Cout, M, N, m0 + wm * 128, n0 + wn * 64, smem + wave * kEpiSlab, lane);
 }
 
-
-int g_gemm_tile_group = -1;    // tuning hook: -1 auto, 0 strip order, n = column groups of n tiles
-
-template <int EPI, int F = 0>
+template <int EPI>
 static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, hipStream_t st) {
-    constexpr int LDS = (8 * kEpiSlab > 2 * 4 * 16384 ? 8 * kEpiSlab : 2 * 4 * 16384) + 8 * 256;   // + residual-prefetch sink
-    auto kern = gemm_bf16_pp_kernel<EPI, F>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    constexpr int LDS = 8 * kEpiSlab > 2 * 4 * 16384 ? 8 * kEpiSlab : 2 * 4 * 16384;
+    auto kern = gemm_bf16_pp_kernel<EPI>;
+    HMM_ENSURE_DYN_LDS(kern, LDS);
     const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
-    int gn = g_gemm_tile_group;
-    if (gn < 0) gn = 0;      // 0 = one group (strip order): the default, see the kernel's comment on the tile walk
-    kern<<<tiles_m * tiles_n, 512, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n, gn);
+    kern<<<tiles_m * tiles_n, 512, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n HMM_PROBE_VAL);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
@@ -613,12 +488,7 @@ template <int BM, int BN, int WM, int WN, int EPI>
 static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, hipStream_t st) {
     constexpr int LDS = 2 * (BM + BN) * 128;
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    HMM_ENSURE_DYN_LDS(kern, LDS);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
     kern<<<tiles_m * tiles_n, WM * WN * 64, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n);
     HMM_LAUNCH_CHECK();
@@ -638,44 +508,21 @@ static int launch_gemm_epi(const bf16_t* A, const bf16_t* W, const float* bias, 
     return HMM_E_INVALID;
 }
 
-int g_gemm_default_variant = 4;      // ping-pong 256x256 kernel + peeled tail (see gemm_bf16)
-
 int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int epi,
-              int variant, hipStream_t st) {
+              int tile, hipStream_t st) {
     HMM_REQUIRE(A && W && C, HMM_E_INVALID, "gemm: null pointer");
     HMM_REQUIRE(M >= 1 && N >= 128 && K >= 64 && K % 64 == 0 && N % 128 == 0, HMM_E_INVALID,
                 "gemm: unsupported shape M=%d N=%d K=%d (need K%%64==0, N%%128==0)", M, N, K);
     HMM_REQUIRE(epi == HMM_EPI_F32 || bias != nullptr, HMM_E_INVALID, "gemm: epilogue %d needs a bias", epi);
-    if (variant < 0) variant = g_gemm_default_variant;
-    if (variant == 3 && (N % 256 != 0 || K % 128 != 0)) variant = 2;
-    if (variant == 2 && N % 256 != 0) variant = 1;
-    if (variant == 2024) {                                                               // A/B: 4 WITH the residual-prefetch experiment
-        if (epi == HMM_EPI_BIAS_RESID_F32 && N % 256 == 0 && K % 128 == 0 && (long)((M + 255) / 256) * (N / 256) >= 128)
-            return launch_gemm_pp<HMM_EPI_BIAS_RESID_F32, 1024>(A, W, bias, C, M, N, K, st);
-        variant = 4;
-    }
-    if (variant >= 100 && epi == HMM_EPI_BIAS_BF16 && N % 256 == 0 && K % 128 == 0) {   // experiment builds
-        switch (variant - 100) {
-            case 1:  return launch_gemm_pp<HMM_EPI_BIAS_BF16, 1>(A, W, bias, C, M, N, K, st);
-            case 2:  return launch_gemm_pp<HMM_EPI_BIAS_BF16, 2>(A, W, bias, C, M, N, K, st);
-            case 4:  return launch_gemm_pp<HMM_EPI_BIAS_BF16, 4>(A, W, bias, C, M, N, K, st);
-            case 8:  return launch_gemm_pp<HMM_EPI_BIAS_BF16, 8>(A, W, bias, C, M, N, K, st);
-            case 16: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 16>(A, W, bias, C, M, N, K, st);
-            case 24: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 24>(A, W, bias, C, M, N, K, st);
-            case 32: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 32>(A, W, bias, C, M, N, K, st);
-            case 64: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 64>(A, W, bias, C, M, N, K, st);
-            case 128: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 128>(A, W, bias, C, M, N, K, st);
-            case 256: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 256>(A, W, bias, C, M, N, K, st);
-            case 512: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 512>(A, W, bias, C, M, N, K, st);
-            case 56: return launch_gemm_pp<HMM_EPI_BIAS_BF16, 56>(A, W, bias, C, M, N, K, st);
-        }
-    }
-    if (variant == 4) {
+    if (tile < 0) tile = HMM_GEMM_TILE_PP_PEELED;
+    const bool pp_ok = N % 256 == 0 && K % 128 == 0;
+    if ((tile == HMM_GEMM_TILE_PP_PEELED || tile == HMM_GEMM_TILE_256x256_PP) && !pp_ok) tile = HMM_GEMM_TILE_256x256;
+    if (tile == HMM_GEMM_TILE_256x256 && N % 256 != 0) tile = HMM_GEMM_TILE_256x128;
+    if (tile == HMM_GEMM_TILE_PP_PEELED) {
         // Tile quantisation: with 256 CUs and one 256x256 tile per CU, T tiles take ceil(T/256) rounds.
         // ViT-H at batch 256 has 257 M-tiles (257 = 256 patches + cls per image), i.e. 5..20 tiles left
         // over for a whole extra round.  Peel the last M-tile(s) off into a small-tile launch when that
         // makes the main launch an exact number of rounds.
-        if (N % 256 != 0 || K % 128 != 0) return gemm_bf16(A, W, bias, C, M, N, K, epi, 2, st);
         const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
         const long tiles = (long)tiles_m * tiles_n;
         // few 256x256 tiles (cls-only last block, head): 128x128 tiles put 4x more CUs to work
@@ -692,13 +539,13 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         return launch_gemm_epi<128, 128, 2, 2>(A + (size_t)m_main * K, W, bias,
                                                static_cast<char*>(C) + (size_t)m_main * N * esz, M - m_main, N, K, epi, st);
     }
-    switch (variant) {
-        case 3: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, st);
-        case 0: return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
-        case 1: return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
-        case 2: return launch_gemm_epi<256, 256, 2, 4>(A, W, bias, C, M, N, K, epi, st);
+    switch (tile) {
+        case HMM_GEMM_TILE_256x256_PP: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_128x128:    return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_256x128:    return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_256x256:    return launch_gemm_epi<256, 256, 2, 4>(A, W, bias, C, M, N, K, epi, st);
     }
-    set_error("gemm: unknown variant %d", variant);
+    set_error("gemm: unknown tile geometry %d", tile);
     return HMM_E_INVALID;
 }
 
@@ -709,15 +556,11 @@ using namespace hmm;
 extern "C" int hmm_op_gemm_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev, void* c_dev,
                                 int M, int N, int K, int epilogue, hmm_stream_t stream) {
     return gemm_bf16(reinterpret_cast<const bf16_t*>(a_dev), reinterpret_cast<const bf16_t*>(w_dev), bias_dev, c_dev,
-                     M, N, K, epilogue, -1, static_cast<hipStream_t>(stream));
+                     M, N, K, epilogue, HMM_GEMM_TILE_AUTO, static_cast<hipStream_t>(stream));
 }
 
-// Tuning hook (not part of the public header): run a specific tile geometry.
-extern "C" int hmm_dev_gemm_bf16_variant(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
-                                         void* c_dev, int M, int N, int K, int epilogue, int variant,
-                                         hmm_stream_t stream) {
+extern "C" int hmm_op_gemm_bf16_tile(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
+                                     void* c_dev, int M, int N, int K, int epilogue, int tile, hmm_stream_t stream) {
     return gemm_bf16(reinterpret_cast<const bf16_t*>(a_dev), reinterpret_cast<const bf16_t*>(w_dev), bias_dev, c_dev,
-                     M, N, K, epilogue, variant, static_cast<hipStream_t>(stream));
+                     M, N, K, epilogue, tile, static_cast<hipStream_t>(stream));
 }
-extern "C" void hmm_dev_set_gemm_variant(int variant) { g_gemm_default_variant = variant; }
-extern "C" void hmm_dev_set_gemm_tile_group(int gn) { hmm::g_gemm_tile_group = gn; }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/hippomm_hip.h"
 
 namespace hmm {
@@ -35,6 +36,32 @@ void set_error(const char* fmt, ...);
 #define HMM_LAUNCH_CHECK() HMM_HIP_CHECK(hipGetLastError())
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Kernels that need more than 64 KiB of dynamic LDS must raise the limit once per (kernel, DEVICE): the attribute is
+// per device, so a second GPU in the same process needs its own call.  One static bit mask per call site (= per kernel
+// instantiation); the launch functions are otherwise stateless.
+#define HMM_ENSURE_DYN_LDS(kern, bytes)                                                                  \
+    do {                                                                                                 \
+        static std::atomic<uint64_t> _hmm_attr_done{0};                                                  \
+        int _hmm_dev = 0;                                                                                \
+        HMM_HIP_CHECK(hipGetDevice(&_hmm_dev));                                                          \
+        const uint64_t _hmm_bit = 1ull << (_hmm_dev & 63);                                               \
+        if (!(_hmm_attr_done.load(std::memory_order_acquire) & _hmm_bit)) {                              \
+            HMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)));     \
+            _hmm_attr_done.fetch_or(_hmm_bit, std::memory_order_release);                                \
+        }                                                                                                \
+    } while (0)
+
+// Tuning knobs exist only in the probe build (tools/, -DHMM_PROBE: libhippomm_probe.so); in the product library they
+// are compile-time constants and no setter is exported.
+#ifdef HMM_PROBE
+#define HMM_TUNABLE(type, name, value) \
+    type name = value;                 \
+    extern "C" void hmm_probe_set_##name(type v) { name = v; }
+#else
+#define HMM_TUNABLE(type, name, value) static constexpr type name = value;
+#endif
 
 // ---- bf16 ------------------------------------------------------------------------------
 typedef __bf16 bf16_t;

@@ -102,7 +102,16 @@ class HipTower:
             pass
 
     def flops(self, batch: int) -> float:
+        """FLOPs of one forward as the reference computes it (the roofline figure)."""
         return float(self._lib.hmm_encoder_flops(self._h, batch))
+
+    def flops_executed(self, batch: int) -> float:
+        """FLOPs this build executes for the same forward (folded patch conv, cls-only last block)."""
+        return float(self._lib.hmm_encoder_flops_executed(self._h, batch))
+
+    def set_streams(self, n: int):
+        """2 (default): half-batches on two streams from batch*clips >= 64 on; 1: a single chain."""
+        _lib.check(self._lib.hmm_encoder_set_streams(self._h, int(n)), "hmm_encoder_set_streams")
 
     def _workspace(self, batch: int) -> torch.Tensor:
         need = self._lib.hmm_encoder_workspace_bytes(self._h, batch)
@@ -114,9 +123,10 @@ class HipTower:
     def forward_into(self, x: torch.Tensor, out: torch.Tensor):
         """x: (b, *INPUT_SHAPE) fp32 contiguous CUDA; out: (b,1024) fp32 CUDA.  Asynchronous."""
         b = x.shape[0]
-        ws = self._workspace(b)
-        _lib.check(self._lib.hmm_encoder_forward(self._h, x.data_ptr(), b, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                 _lib.stream_ptr()), "hmm_encoder_forward")
+        with torch.cuda.device(self.device):          # the handle's streams / events / weights live on self.device
+            ws = self._workspace(b)
+            _lib.check(self._lib.hmm_encoder_forward(self._h, x.data_ptr(), b, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                     _lib.stream_ptr()), "hmm_encoder_forward")
 
     def __call__(self, x: torch.Tensor, max_batch: int = 256) -> torch.Tensor:
         if tuple(x.shape[1:]) != INPUT_SHAPE[self.name]:

@@ -147,8 +147,16 @@ size_t hmm_encoder_workspace_bytes(const hmm_encoder* enc, int batch);
  * out_dev:   (batch,1024) fp32 */
 int  hmm_encoder_forward(hmm_encoder* enc, const void* input_dev, int batch, float* out_dev,
                          void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
-/* FLOPs (2 x MAC) one forward of `batch` samples performs, for roofline accounting. */
+/* FLOPs (2 x MAC) of one forward of `batch` samples as the REFERENCE computes it (un-folded patch convolution, every
+ * block on every token: SURVEY 8d's 334.98 GFLOP per vision frame) -- the figure roofline fractions are quoted on. */
 double hmm_encoder_flops(const hmm_encoder* enc, int batch);
+/* FLOPs this build actually executes for the same forward: temporal taps of the Conv3d folded into one K-padded matrix,
+ * and the last block computed for the selected row only (vision / audio: K,V for every token, the rest for token 0). */
+double hmm_encoder_flops_executed(const hmm_encoder* enc, int batch);
+/* n_streams = 2 (default): from batch*clips >= 64 on, a forward runs as two half-batches, the second on a stream owned
+ * by the handle (forked from / joined to the caller's stream with events).  n_streams = 1: one chain on the caller's
+ * stream only.  Embeddings are bitwise identical either way (tests/test_gpu_encoder_batch.py). */
+int  hmm_encoder_set_streams(hmm_encoder* enc, int n_streams);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side vision preprocessing.  Replaces, for already decoded frames, the transform chain of
@@ -199,6 +207,17 @@ int    hmm_audio_fbank(const float* clips_dev, int n_clips, int clip_len, int64_
  * Rows of A beyond M are never read; rows of C beyond M are never written. */
 int hmm_op_gemm_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
                      void* c_dev, int M, int N, int K, int epilogue, hmm_stream_t stream);
+/* The same product on one named tile geometry (hmm_op_gemm_bf16 picks per shape), so that every kernel the dispatcher
+ * can choose is parity-tested on every shape.  Every geometry adds the K products of an output element in the same
+ * order, so results are bitwise equal across geometries. */
+#define HMM_GEMM_TILE_AUTO       -1
+#define HMM_GEMM_TILE_128x128     0  /* 4 waves, double-buffered LDS-DMA                                  */
+#define HMM_GEMM_TILE_256x128     1
+#define HMM_GEMM_TILE_256x256     2  /* 8 waves, same loop                                                */
+#define HMM_GEMM_TILE_256x256_PP  3  /* 8 waves, 4-phase ping-pong, counted vmcnt; needs N%256==0, K%128==0 */
+#define HMM_GEMM_TILE_PP_PEELED   4  /* what AUTO uses for large shapes: PP on whole rounds + 128x128 tail */
+int hmm_op_gemm_bf16_tile(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
+                          void* c_dev, int M, int N, int K, int epilogue, int tile, hmm_stream_t stream);
 /* y_bf16[rows, D] = LayerNorm(x_f32[rows, D]) * gamma + beta ; D in {768, 1280} */
 int hmm_op_layernorm_bf16(const float* x_dev, const float* gamma_dev, const float* beta_dev,
                           uint16_t* y_dev, int rows, int D, float eps, hmm_stream_t stream);
@@ -208,6 +227,17 @@ int hmm_op_layernorm_bf16(const float* x_dev, const float* gamma_dev, const floa
 int hmm_op_attention_bf16(const uint16_t* qkv_dev, uint16_t* out_dev, int batch, int tokens,
                           int heads, int head_dim, const float* bias_k_dev, const float* bias_v_dev,
                           hmm_stream_t stream);
+/* Causal variant (text tower): key j is visible to query i iff j <= i; no bias_kv. */
+int hmm_op_attention_causal_bf16(const uint16_t* qkv_dev, uint16_t* out_dev, int batch, int tokens,
+                                 int heads, int head_dim, hmm_stream_t stream);
+
+/* Timing / test hooks of the scan (bench.py roofline, tests): the streaming kernel of hmm_cosine_topk alone --
+ * scan_topk_kernel writing its per-block candidate keys (cand_keys_dev: 2048*k uint64) -- and the plain similarity
+ * pass (sims_dev: n_rows fp32) that k > 128 uses. */
+int hmm_op_scan_topk_only(const float* store_dev, int64_t n_rows, const float* query_dev, int k,
+                          uint64_t* cand_keys_dev, hmm_stream_t stream);
+int hmm_op_scan_sims(const float* store_dev, int64_t n_rows, const float* query_dev, float* sims_dev,
+                     hmm_stream_t stream);
 
 #ifdef __cplusplus
 }

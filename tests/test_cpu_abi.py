@@ -26,11 +26,22 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, f"declared in the header but not exported: {missing}"
 
 
+def test_library_exports_nothing_but_the_header():
+    """No tuning setters, experiment variants or probe hooks in the product library: its dynamic hmm_* symbols are
+    exactly the ones include/hippomm_hip.h declares (probe builds live in tools/, libhippomm_probe.so)."""
+    import subprocess
+    from hippomm_amd import build
+    out = subprocess.run(["nm", "-D", "--defined-only", str(build.build())], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("hmm_")})
+    assert exported == _declared_symbols(), sorted(set(exported) ^ set(_declared_symbols()))
+    assert not [n for n in exported if n.startswith(("hmm_dev_", "hmm_probe_"))]
+
+
 def test_binding_table_matches_header():
     from hippomm_amd import _lib
     assert sorted(_lib._SIGNATURES) == _declared_symbols()
     lib = _lib.load()
-    assert lib.hmm_abi_version() == 1
+    assert lib.hmm_abi_version() == 2
     assert lib.hmm_cosine_topk_workspace_bytes(1_000_000, 32) > 4_000_000
     assert lib.hmm_gram_select_workspace_bytes(3600) > 3648 * 1024 * 4
 

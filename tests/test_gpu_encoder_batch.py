@@ -1,0 +1,144 @@
+"""GPU parity of the towers at the batch sizes that production and bench.py actually run.
+
+From batch*clips >= 64 on, ``hmm_encoder_forward`` forks into two half-batches on two streams
+(second workspace half, 256x256 ping-pong GEMM with the peeled last row tile, XCD-dealt attention
+grid over many images).  The small-batch tests in test_gpu_encoder.py never reach that path, so
+these do, at BASELINE cfg 2 (vision B=256) and cfg 3 (128 frame + audio pairs):
+
+  * reduced depth vs the fp32 oracle on EVERY row (tolerance as in test_gpu_encoder.py);
+  * full depth: bitwise equality with the same frames pushed through the single-stream small-batch
+    path (max_batch=32 / 16), which IS oracle-checked row by row -- a per-frame result must not
+    depend on the batch it rides in, the stream it ran on or the GEMM tile geometry;
+  * odd splits (70 -> 35/35, 71 -> 35/36) and the single-stream A/B through hmm_encoder_set_streams.
+
+Reference call shapes: foundation_models.py:116-133, hippocampal_memory.py:1328-1331 (32-frame buffer),
+:1180-1183 (per segment)."""
+import pytest
+import torch
+
+from oracle import imagebind_oracle as ib
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 2e-4
+ABS_TOL = 2e-2
+
+
+def _check(got, want, scale=1.0, what=""):
+    got, want = got.float().cpu(), want.float().cpu()
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    cos = torch.nn.functional.cosine_similarity(got, want, dim=1)
+    err = (got - want).abs().max().item()
+    print(f"{what}: rows {got.shape[0]}  min cos {cos.min().item():.7f}  max|diff| {err:.3e}")
+    assert (1 - cos).max().item() <= COS_TOL
+    assert err <= ABS_TOL * scale
+
+
+def _frames(n, seed=0):
+    return torch.randn(n, 3, 224, 224, generator=torch.Generator().manual_seed(seed))
+
+
+def test_vision_depth2_batch256_vs_oracle_every_row():
+    """BASELINE cfg 2 batch through the two-stream path; oracle on all 256 rows (~10 s of CPU)."""
+    from hippomm_amd.encoder import HipTower
+    spec = ib.reduced(ib.VISION_HUGE, 2)
+    st = ib.synthetic_state(spec, seed=1234, init="rich")
+    x = _frames(256)
+    want = ib.vision_forward(x, st, spec)
+    tower = HipTower("vision", st, depth=2)
+    got = tower(x)
+    _check(got, want, what="vision depth2 B=256 (two streams)")
+    # the same rows through the single-chain small-batch path
+    assert torch.equal(got, tower(x, max_batch=32)), "two-stream B=256 differs from single-stream chunks of 32"
+
+
+def test_audio_depth2_batch128_vs_oracle_every_row():
+    """BASELINE cfg 3 audio half: 128 segments = 384 clips, two streams of 64 segments."""
+    from hippomm_amd.encoder import HipTower
+    spec = ib.reduced(ib.AUDIO_HUGE, 2)
+    st = ib.synthetic_state(spec, seed=4321, init="rich")
+    mels = torch.randn(128, 3, 1, 128, 204, generator=torch.Generator().manual_seed(1))
+    want = ib.audio_forward(mels, st, spec)
+    tower = HipTower("audio", st, depth=2)
+    got = tower(mels)
+    _check(got, want, scale=20.0, what="audio depth2 B=128 (two streams)")
+    assert torch.equal(got, tower(mels, max_batch=16))
+
+
+@pytest.mark.parametrize("batch", [64, 70, 71, 129])
+def test_vision_odd_splits_bitwise_and_oracle(batch):
+    """The smallest forked batch, even and odd splits, and one frame past a half-batch tile boundary."""
+    from hippomm_amd.encoder import HipTower
+    spec = ib.reduced(ib.VISION_HUGE, 1)
+    st = ib.synthetic_state(spec, seed=9, init="rich")
+    x = _frames(batch, seed=5)
+    tower = HipTower("vision", st, depth=1)
+    got = tower(x)
+    assert torch.equal(got, tower(x, max_batch=8))
+    pick = sorted({0, 1, batch // 2 - 1, batch // 2, batch - 1})          # both sides of the split and the ends
+    _check(got[pick], ib.vision_forward(x[pick], st, spec), what=f"vision depth1 B={batch} rows {pick}")
+
+
+def test_audio_odd_split():
+    from hippomm_amd.encoder import HipTower
+    spec = ib.reduced(ib.AUDIO_HUGE, 1)
+    st = ib.synthetic_state(spec, seed=11, init="rich")
+    mels = torch.randn(23, 3, 1, 128, 204, generator=torch.Generator().manual_seed(2))   # 69 clips -> 11 / 12 segments
+    tower = HipTower("audio", st, depth=1)
+    got = tower(mels)
+    assert torch.equal(got, tower(mels, max_batch=4))
+    pick = [0, 10, 11, 22]
+    _check(got[pick], ib.audio_forward(mels[pick], st, spec), scale=20.0, what="audio depth1 B=23")
+
+
+def test_single_stream_option_is_bitwise_neutral():
+    """hmm_encoder_set_streams(1) runs the same batch as one chain: identical embeddings."""
+    from hippomm_amd.encoder import HipTower
+    spec = ib.reduced(ib.VISION_HUGE, 2)
+    st = ib.synthetic_state(spec, seed=3, init="rich")
+    x = _frames(96, seed=7).cuda()
+    tower = HipTower("vision", st, depth=2)
+    two = tower(x)
+    tower.set_streams(1)
+    one = tower(x)
+    tower.set_streams(2)
+    assert torch.equal(one, two)
+    assert torch.equal(two, tower(x))
+
+
+def test_full_depth_vision_batch256_bitwise_batch_invariance():
+    """32 blocks at BASELINE cfg 2: the benchmarked configuration equals the oracle-checked small-batch path bit for bit,
+    and its first frames match the fp32 oracle."""
+    from hippomm_amd.encoder import HipTower
+    st = ib.synthetic_state(ib.VISION_HUGE, seed=1234, init="survey")
+    x = _frames(256)
+    tower = HipTower("vision", st)
+    big = tower(x)
+    assert torch.equal(big, tower(x, max_batch=32))
+    assert torch.equal(big, tower(x))                                       # run-to-run
+    _check(big[:3], ib.vision_forward(x[:3], st), what="vision full depth B=256, rows 0..2")
+    _check(big[253:], ib.vision_forward(x[253:], st), what="vision full depth B=256, rows 253..255")
+
+
+def test_full_depth_audio_batch128_and_text_batch96_bitwise_batch_invariance():
+    from hippomm_amd.encoder import HipTower
+    st = ib.synthetic_state(ib.AUDIO_HUGE, seed=1235, init="survey")
+    mels = torch.randn(128, 3, 1, 128, 204, generator=torch.Generator().manual_seed(1))
+    tower = HipTower("audio", st)
+    big = tower(mels)
+    assert torch.equal(big, tower(mels, max_batch=16))
+    _check(big[[0, 63, 64, 127]], ib.audio_forward(mels[[0, 63, 64, 127]], st), scale=20.0,
+           what="audio full depth B=128")
+    del tower
+    st = ib.synthetic_state(ib.TEXT_HUGE, seed=5, init="survey")
+    g = torch.Generator().manual_seed(0)
+    tok = torch.randint(1, 49000, (96, 77), generator=g)
+    for b in range(96):
+        n = 1 + (b * 7) % 76
+        tok[b, n] = 49407
+        tok[b, n + 1:] = 0
+    tower = HipTower("text", st)
+    big = tower(tok)
+    assert torch.equal(big, tower(tok, max_batch=16))
+    _check(big[[0, 47, 48, 95]], ib.text_forward(tok[[0, 47, 48, 95]], st), scale=1.0 / 0.07,
+           what="text full depth B=96")

@@ -17,10 +17,6 @@ BF16_EPS = 2.0 ** -8          # half an ulp of bf16, relative
 def _lib():
     from hippomm_amd import _lib as L
     lib = L.load()
-    if not hasattr(lib, "_dev_ready"):
-        lib.hmm_dev_gemm_bf16_variant.restype = C.c_int
-        lib.hmm_dev_gemm_bf16_variant.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
-        lib._dev_ready = True
     return L, lib
 
 
@@ -48,7 +44,7 @@ def test_gemm_bias_bf16(variant, M, N, K):
     want = a.float() @ w.float().T + bias
     ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
     c = torch.full((M + 3, N), float("nan"), dtype=torch.bfloat16, device="cuda")   # canary rows past M
-    L.check(lib.hmm_dev_gemm_bf16_variant(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), c.data_ptr(), M, N, K,
+    L.check(lib.hmm_op_gemm_bf16_tile(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), c.data_ptr(), M, N, K,
                                           EPI_BIAS_BF16, variant, L.stream_ptr()), "gemm")
     _close_bf16(c[:M], want)
     assert torch.isnan(c[M:].float()).all(), "rows past M were written"
@@ -66,18 +62,18 @@ def test_gemm_gelu_resid_f32_epilogues(variant):
     ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
     # GELU(erf)
     c = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    L.check(lib.hmm_dev_gemm_bf16_variant(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), c.data_ptr(), M, N, K,
+    L.check(lib.hmm_op_gemm_bf16_tile(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), c.data_ptr(), M, N, K,
                                           EPI_BIAS_GELU_BF16, variant, L.stream_ptr()), "gemm gelu")
     _close_bf16(c, F.gelu(lin), extra_atol=2e-5)
     # fp32 residual, in place
     x0 = torch.randn(M, N, generator=g)
     x = x0.clone().cuda()
-    L.check(lib.hmm_dev_gemm_bf16_variant(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), x.data_ptr(), M, N, K,
+    L.check(lib.hmm_op_gemm_bf16_tile(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), x.data_ptr(), M, N, K,
                                           EPI_BIAS_RESID_F32, variant, L.stream_ptr()), "gemm resid")
     torch.testing.assert_close(x.cpu(), x0 + lin, rtol=2e-5, atol=2e-4)
     # plain fp32, no bias
     y = torch.empty(M, N, dtype=torch.float32, device="cuda")
-    L.check(lib.hmm_dev_gemm_bf16_variant(ad.data_ptr(), wd.data_ptr(), None, y.data_ptr(), M, N, K,
+    L.check(lib.hmm_op_gemm_bf16_tile(ad.data_ptr(), wd.data_ptr(), None, y.data_ptr(), M, N, K,
                                           EPI_F32, variant, L.stream_ptr()), "gemm f32")
     torch.testing.assert_close(y.cpu(), lin - bias, rtol=2e-5, atol=2e-4)
 
@@ -95,19 +91,19 @@ def test_gemm_many_tiles_ragged_m(epi):
     lin = a.float() @ w.float().T
     if epi in (EPI_BIAS_BF16, EPI_BIAS_GELU_BF16):
         c = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
-        L.check(lib.hmm_dev_gemm_bf16_variant(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K,
+        L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K,
                                               epi, 4, L.stream_ptr()), "gemm")
         want = lin + bias
         _close_bf16(c, F.gelu(want) if epi == EPI_BIAS_GELU_BF16 else want, extra_atol=2e-5)
     elif epi == EPI_BIAS_RESID_F32:
         x0 = torch.randn(M, N, device="cuda", generator=g)
         x = x0.clone()
-        L.check(lib.hmm_dev_gemm_bf16_variant(a.data_ptr(), w.data_ptr(), bias.data_ptr(), x.data_ptr(), M, N, K,
+        L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), x.data_ptr(), M, N, K,
                                               epi, 4, L.stream_ptr()), "gemm")
         torch.testing.assert_close(x, x0 + lin + bias, rtol=2e-5, atol=2e-4)
     else:
         y = torch.empty(M, N, dtype=torch.float32, device="cuda")
-        L.check(lib.hmm_dev_gemm_bf16_variant(a.data_ptr(), w.data_ptr(), None, y.data_ptr(), M, N, K,
+        L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), None, y.data_ptr(), M, N, K,
                                               epi, 4, L.stream_ptr()), "gemm")
         torch.testing.assert_close(y, lin, rtol=2e-5, atol=2e-4)
 
@@ -144,7 +140,7 @@ def test_gemm_identity_asymmetric():
     ad, wd = a.cuda(), w.cuda()
     for variant in (0, 1, 2, 3, 4):
         y.zero_()
-        L.check(lib.hmm_dev_gemm_bf16_variant(ad.data_ptr(), wd.data_ptr(), None, y.data_ptr(), K, N, K,
+        L.check(lib.hmm_op_gemm_bf16_tile(ad.data_ptr(), wd.data_ptr(), None, y.data_ptr(), K, N, K,
                                               EPI_F32, variant, L.stream_ptr()), "gemm")
         assert torch.equal(y.cpu(), w.float().T)
 
@@ -207,8 +203,6 @@ def test_attention(B, T, H, dh, bias, scale):
 def test_attention_causal(B, T, H):
     """Causal variant (text tower): query i sees keys 0..i."""
     L, lib = _lib()
-    lib.hmm_dev_attention_causal_bf16.restype = C.c_int
-    lib.hmm_dev_attention_causal_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     dh, D = 64, H * 64
     g = torch.Generator().manual_seed(T)
     qkv = (torch.randn(B * T, 3 * D, generator=g) * 3.0).to(torch.bfloat16)
@@ -218,7 +212,7 @@ def test_attention_causal(B, T, H):
     want = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * T, D)
     out = torch.full((B * T, D), float("nan"), dtype=torch.bfloat16, device="cuda")
     qd = qkv.cuda()
-    L.check(lib.hmm_dev_attention_causal_bf16(qd.data_ptr(), out.data_ptr(), B, T, H, dh, L.stream_ptr()), "attention")
+    L.check(lib.hmm_op_attention_causal_bf16(qd.data_ptr(), out.data_ptr(), B, T, H, dh, L.stream_ptr()), "attention")
     got = out.float().cpu()
     tol = 2.0 ** -8 * want.abs() + 2.0 ** -8 * 3.0 + 1e-4
     bad = (got - want).abs() > tol

@@ -4,21 +4,17 @@ sys.path.insert(0, ".")
 import torch
 from hippomm_amd import _lib as L
 lib = L.load()
-lib.hmm_dev_gemm_bf16_variant.restype = C.c_int
-lib.hmm_dev_gemm_bf16_variant.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65792
 variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2]
-groups = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [-1]
 shapes = [("qkv", 3840, 1280, 0), ("out", 1280, 1280, 2), ("fc1", 5120, 1280, 1), ("fc2", 1280, 5120, 2)]
 for name, N, K, epi in shapes:
     a = (torch.randn(M, K, device="cuda")).to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
     bias = torch.zeros(N, device="cuda")
     c = torch.zeros(M, N, device="cuda", dtype=torch.float32 if epi == 2 else torch.bfloat16)
-    for v, gn in [(v, gn) for v in variants for gn in groups]:
-        lib.hmm_dev_set_gemm_tile_group(gn)
+    for v in variants:
         def run():
-            L.check(lib.hmm_dev_gemm_bf16_variant(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(),
+            L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(),
                                                   M, N, K, epi, v, L.stream_ptr()), "gemm")
         for _ in range(3): run()
         torch.cuda.synchronize()
@@ -28,4 +24,4 @@ for name, N, K, epi in shapes:
         for _ in range(it): run()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / it
-        print(f"{name:4s} M={M} N={N} K={K} variant={v} tile_group={gn}: {ms:.3f} ms  {2*M*N*K/ms/1e9:.0f} TFLOP/s", flush=True)
+        print(f"{name:4s} M={M} N={N} K={K} variant={v}: {ms:.3f} ms  {2*M*N*K/ms/1e9:.0f} TFLOP/s", flush=True)

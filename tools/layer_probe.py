@@ -1,11 +1,24 @@
-"""Time every kernel of one ViT-H transformer block in sequence context (B=256) with HIP events,
-several rounds, optional A/B of a tuning flag inside one process.
-usage: layer_probe.py [flag=val,val ...]   flags: attn_reverse, gemm_variant"""
-import ctypes as C, sys
-sys.path.insert(0, ".")
+"""In-situ A/B of tuning knobs of the probe build (tools/libhippomm_probe.so), in ONE process, interleaved rounds:
+  * every kernel of one ViT-H transformer block timed in sequence context (B=256, HIP events around each launch),
+  * the whole 32-block forward at B=256 (two streams), median of the rounds.
+usage: layer_probe.py [knob=v0,v1,...] ... [--no-tower] [--json out.json]
+       knobs are the hmm_probe_set_<knob> setters of the probe build (e.g. g_gemm_dephase_units=0,2,4)."""
+import itertools
+import json
+import sys
+
+from probe_common import load_probe, setter, event_ms
+
 import torch
-from hippomm_amd import _lib as L
-lib = L.load()
+
+L, lib = load_probe()
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+no_tower = "--no-tower" in sys.argv
+json_out = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+args = [a for a in args if a != json_out]
+knobs = [(a.split("=")[0], [int(v) for v in a.split("=")[1].split(",")]) for a in args]
+configs = [dict(zip([k for k, _ in knobs], vals)) for vals in itertools.product(*[v for _, v in knobs])] or [{}]
+
 B, T, D, H, MLP = 256, 257, 1280, 16, 5120
 R = B * T
 dev = "cuda"
@@ -27,11 +40,12 @@ steps = [
     ("fc1", lambda: lib.hmm_op_gemm_bf16(a.data_ptr(), w1.data_ptr(), bb1.data_ptr(), big.data_ptr(), R, MLP, D, 1, S())),
     ("fc2", lambda: lib.hmm_op_gemm_bf16(big.data_ptr(), w2.data_ptr(), bb2.data_ptr(), x.data_ptr(), R, D, MLP, 2, S())),
 ]
-setters = {"attn_reverse": lib.hmm_dev_set_attn_reverse, "gemm_variant": lib.hmm_dev_set_gemm_variant}
-configs = [{}]
-for arg in sys.argv[1:]:
-    k, vs = arg.split("=")
-    configs = [dict(c, **{k: int(v)}) for c in configs for v in vs.split(",")]
+
+
+def apply(cfg):
+    for k, v in cfg.items():
+        setter(lib, k)(v)
+
 
 def run_layers(n_layers):
     evs = []
@@ -46,14 +60,39 @@ def run_layers(n_layers):
         acc.setdefault(name, []).append(e0.elapsed_time(e1) * 1e3)
     return {k: sorted(v)[len(v) // 2] for k, v in acc.items()}
 
-results = {i: [] for i in range(len(configs))}
-for rnd in range(3):
+
+tower = frames = emb = None
+if not no_tower:
+    from hippomm_amd.encoder import HipTower, synthetic_state_dict
+    sd = synthetic_state_dict(("vision",), seed=1234)
+    tower = HipTower("vision", sd)
+    del sd
+    torch.cuda.empty_cache()
+    frames = torch.randn(B, 3, 224, 224, device=dev)
+    emb = torch.empty(B, 1024, device=dev)
+
+ROUNDS = 3
+layer_res = {i: [] for i in range(len(configs))}
+tower_res = {i: [] for i in range(len(configs))}
+for rnd in range(ROUNDS):
     for i, cfg in enumerate(configs):
-        for k, v in cfg.items(): setters[k](v)
+        apply(cfg)
         x.normal_()
         run_layers(2)
-        results[i].append(run_layers(8))
+        layer_res[i].append(run_layers(6))
+        if tower is not None:
+            tower_res[i].append(event_ms(lambda: tower.forward_into(frames, emb), 4, warmup=1))
+out = []
 for i, cfg in enumerate(configs):
-    med = {k: sorted(r[k] for r in results[i])[1] for k in results[i][0]}
+    med = {k: sorted(r[k] for r in layer_res[i])[ROUNDS // 2] for k in layer_res[i][0]}
     tot = sum(med.values())
-    print(cfg, " ".join(f"{k}={v:.0f}" for k, v in med.items()), f"| layer={tot:.0f} us  x32={tot*32/1e3:.1f} ms", flush=True)
+    rec = {"cfg": cfg, "layer_us": {k: round(v) for k, v in med.items()}, "layer_total_us": round(tot)}
+    if tower is not None:
+        t = sorted(tower_res[i])
+        rec["forward_ms_median"] = round(t[ROUNDS // 2], 2)
+        rec["forward_ms_min"] = round(t[0], 2)
+        rec["img_per_s"] = round(B / t[ROUNDS // 2] * 1e3)
+    out.append(rec)
+    print(rec, flush=True)
+if json_out:
+    json.dump(out, open(json_out, "w"), indent=1)
