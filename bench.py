@@ -1,34 +1,49 @@
 #!/usr/bin/env python3
 """Benchmark of the HippoMM hot path on MI355X (contract: see the round brief).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): ImageBind-huge ViT-H/14 vision tower, bf16 MFMA, 256 synthetic
-224x224 frames per GPU per step.  A step = one pass of the path over one batch: encode the local 256
-frames -> (N > 1: one RCCL all-gather of the (256,1024) fp32 embeddings) -> cosine key-frame
-selection on the gathered matrix.  Weak scaling: per-GPU work is fixed, value = N*256*K / time.
+`--gpus N` with N > 1 and no torchrun environment launches the N ranks itself: the parent process never touches the
+GPU, starts `python -m torch.distributed.run` as a child, exits non-zero when fewer than N GPUs are visible and
+returns the child's exit code.  A rank whose WORLD_SIZE disagrees with --gpus refuses to run.
 
-The same JSON line also carries the second half of BASELINE's metric under "scan": the feature_search
-scan over a resident 1M x 1024 fp32 store (k=32) in GB/s of algorithmic bytes (4096 B per row).
+Workloads
+  cfg2 (default; BASELINE.json configs[1]): ImageBind-huge ViT-H/14 vision tower, bf16 MFMA, 256 synthetic 224x224
+        frames per GPU per step.  A step = one pass of the path over one batch: encode the local 256 frames ->
+        (N > 1: one RCCL all-gather of the (256,1024) fp32 embeddings) -> cosine key-frame selection on the
+        gathered matrix.  Weak scaling: per-GPU work is fixed, value = N*256*K / time.
+  cfg5 (BASELINE.json configs[4]): a 1-hour video at 1 fps = 3600 frames in contiguous time shards of ceil(3600/N)
+        frames per rank -> encode -> ONE all-gather -> global selection on every rank.  Strong scaling: total work
+        is fixed, value = 3600*K / time; the line also carries the all-gather time and whether the kept indices
+        equal the CPU oracle's on the same gathered matrix.
+The frames are synthetic "scenes": a low-frequency random pattern per scene (6 consecutive frames) plus pixel noise,
+so that the random-init tower yields distinct embeddings per scene and the timed selection really drops frames.
+
+At N = 1 (cfg2) the same JSON line carries the second half of BASELINE's metric under "scan" (the feature_search scan
+over a resident 1M x 1024 fp32 store, k = 32, GB/s of algorithmic bytes), BASELINE cfg 3 under "joint_vision_audio",
+the consolidation timings and the CPU baselines of BASELINE.md section 4.
 
 roofline      : the dominant kernel of the step (the bf16 GEMM instance with the largest time share),
                 algorithmic FLOPs per launch / mean launch time measured live with HIP events on the
-                launch stream; peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).
+                launch stream; peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md); traffic is read from the
+                committed PMC summary under profiles/ (null when there is none for this kernel).
 cpu_baseline  : the fp32 oracle of the same tower (oracle/imagebind_oracle.py, torch CPU) timed on this
                 host's cores on a bounded sample, rank 0, N=1 only.  A reported baseline, not a target.
+parity_vs_oracle : rows of the TIMED batch (both halves of the two-stream split) against the fp32 oracle.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -37,8 +52,69 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
-FRAMES_PER_GPU = 256
+FRAMES_PER_GPU = 256           # cfg2
+CFG5_FRAMES = 3600             # cfg5: one hour at 1 fps
+SCENE_LEN = 6                  # frames per synthetic scene
 SCAN_ROWS, SCAN_K = 1_000_000, 32
+
+
+# ------------------------------------------------------------------------------------------------
+# launching
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(n: int, argv) -> int:
+    """Parent of a self-launched multi-GPU run.  Must not initialise the GPU: device_count() does not."""
+    visible = torch.cuda.device_count()
+    if visible < n:
+        print(f"bench.py: --gpus {n} but only {visible} GPU(s) visible", file=sys.stderr)
+        return 3
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic input and the step (also driven on CPU / gloo by tests/test_cpu_bench_step.py)
+# ------------------------------------------------------------------------------------------------
+def synthetic_frames(lo: int, hi: int, device, amp: float = 1.5, sigma: float = 0.3) -> torch.Tensor:
+    """Frames lo..hi-1 of the synthetic video, identical whatever the sharding: scene s = frame // SCENE_LEN is a
+    low-frequency pattern (4x4 random field, bilinear to 224x224, seeded by s), each frame adds pixel noise seeded
+    by its own index.  Stands for CLIP-normalised pixels, i.e. post-load_data."""
+    out = torch.empty(hi - lo, 3, 224, 224, dtype=torch.float32, device=device)
+    scene, scene_id = None, -1
+    for i in range(lo, hi):
+        s = i // SCENE_LEN
+        if s != scene_id:
+            g = torch.Generator().manual_seed(1000 + s)
+            base = torch.randn(1, 3, 4, 4, generator=g) * amp
+            scene = torch.nn.functional.interpolate(base, size=(224, 224), mode="bilinear", align_corners=False)[0]
+            scene_id = s
+        g = torch.Generator().manual_seed(7_000_000 + i)
+        out[i - lo] = (scene + sigma * torch.randn(3, 224, 224, generator=g)).to(device)
+    return out
+
+
+def make_step(frames_local, counts, encode_fn, gather_fn, select_fn):
+    """One pass of the hot path over this rank's batch: encode -> all-gather -> global key-frame selection."""
+    def step():
+        emb = encode_fn(frames_local)
+        feats = gather_fn(emb, counts)
+        return feats, select_fn(feats)
+    return step
+
+
+def timed_steps(step, steps: int, warmup: int, sync, barrier, reduce_max):
+    """The timing contract: W untimed steps, then exactly K steps bracketed by barrier + device sync, max over ranks."""
+    last = None
+    for _ in range(warmup):
+        last = step()
+    sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    sync(); barrier(); sync()
+    return reduce_max(time.perf_counter() - t0), last
 
 
 def event_time_ms(fn, iters, warmup=2):
@@ -54,10 +130,24 @@ def event_time_ms(fn, iters, warmup=2):
     return e0.elapsed_time(e1) / iters
 
 
+def profile_summary(pattern: str, kernel: str):
+    """Newest committed PMC summary under profiles/ that names `kernel` -> (traffic bytes per launch, file) or (None, None)."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if doc.get("kernel") == kernel and "traffic_bytes_per_launch" in doc:
+            return int(doc["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# N = 1 extras
+# ------------------------------------------------------------------------------------------------
 def gemm_roofline(rows):
     """Time each GEMM instance of one transformer block at the step's row count; return the
     roofline object of the dominant one plus the per-kernel table."""
-    import ctypes as C
     from hippomm_amd import _lib as L
     lib = L.load()
     shapes = [("qkv_proj", 3840, 1280, 0), ("out_proj+residual", 1280, 1280, 2),
@@ -78,21 +168,19 @@ def gemm_roofline(rows):
                       "tflops": round(flops / ms / 1e9, 1), "launches_per_step": 32})
         del a, w, c
     dom = max(table, key=lambda r: r["ms"])
+    traffic, src = profile_summary("r*_gemm_pmc_summary.json", dom["kernel"]) if rows == 65792 else (None, None)
+    out_bytes = 8 if "residual" in dom["kernel"] else 2           # fp32 read-modify-write / bf16 store, per element
     roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "flops_per_launch": 2.0 * dom["M"] * dom["N"] * dom["K"], "ms_per_launch": dom["ms"]}
-    if dom["kernel"] == "gemm_bf16[mlp_fc1+gelu]" and rows == 65792:
-        # PMC passes (profiles/r1_gemm_pmc_summary.json): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, main + peeled
-        # launch.  These are fabric-side requests, Infinity-Cache hits included: 4.9x the operand bytes because the strip
-        # tile walk streams the 13-MB weight matrix once per 256-row tile (cache traffic, the kernel is MFMA-bound).
-        roof["traffic"] = 4156223882
-        roof["traffic_source"] = "profiles/r1_gemm_pmc_summary.json"
-        roof["algorithmic_bytes_per_launch"] = 2 * (rows * 1280 + 5120 * 1280 + rows * 5120)
+            "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": src, "flops_per_launch": 2.0 * dom["M"] * dom["N"] * dom["K"],
+            "ms_per_launch": dom["ms"],
+            "algorithmic_bytes_per_launch": 2 * (dom["M"] * dom["K"] + dom["N"] * dom["K"]) + dom["M"] * dom["N"] * out_bytes}
     return roof, table
 
 
 def scan_bench(do_cpu):
     from hippomm_amd.vector_ops import FeatureStore
+    from hippomm_amd import _lib as L
     g = torch.Generator(device="cuda").manual_seed(42)
     rows = torch.empty(SCAN_ROWS, 1024, dtype=torch.float32, device="cuda")
     for s in range(0, SCAN_ROWS, 125_000):
@@ -102,21 +190,19 @@ def scan_bench(do_cpu):
     store = FeatureStore(rows)
     ms_query = event_time_ms(lambda: store.search_device(q, SCAN_K), 20, warmup=3)
     # the streaming kernel alone (dominant kernel of the scan)
-    import ctypes as C
-    from hippomm_amd import _lib as L
     lib = L.load()
     cand = torch.empty(2048 * SCAN_K, dtype=torch.int64, device="cuda")
     ms_kernel = event_time_ms(lambda: L.check(lib.hmm_op_scan_topk_only(rows.data_ptr(), SCAN_ROWS, q.data_ptr(), SCAN_K,
-                                                                         cand.data_ptr(), L.stream_ptr()), "scan"), 20)
+                                                                        cand.data_ptr(), L.stream_ptr()), "scan"), 20)
     algo_bytes = SCAN_ROWS * 4096.0
+    traffic, src = profile_summary("r*_scan_pmc_summary.json", "scan_topk_kernel")
     out = {
         "metric": "cosine-scan GB/s (feature_search, 1M x 1024 fp32 store, top-32, 1 query)",
         "value": round(algo_bytes / ms_query / 1e6, 1), "unit": "GB/s", "ms_per_query": round(ms_query, 4),
         "dtype": "f32",
         "roofline": {"bound": "hbm", "kernel": "scan_topk_kernel", "achieved": round(algo_bytes / ms_kernel / 1e6, 1),
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(algo_bytes / ms_kernel / 1e6 / PEAK_HBM_GBS, 4),
-                     # PMC pass (profiles/r1_scan_pmc_summary.json): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE
-                     "traffic": 4096643072, "traffic_source": "profiles/r1_scan_pmc_summary.json",
+                     "traffic": traffic, "traffic_source": src,
                      "bytes_per_launch": algo_bytes, "ms_per_launch": round(ms_kernel, 4)},
     }
     # batched questions: 16 queries per pass over the same store
@@ -124,6 +210,7 @@ def scan_bench(do_cpu):
     ms_multi = event_time_ms(lambda: store.search_multi_device(q16, SCAN_K), 10, warmup=3)
     out["batched_16_queries"] = {"ms_per_pass": round(ms_multi, 4), "us_per_query": round(ms_multi / 16 * 1e3, 1),
                                  "store_read_GBps": round(algo_bytes / ms_multi / 1e6, 1),
+                                 "hbm_frac": round(algo_bytes / ms_multi / 1e6 / PEAK_HBM_GBS, 4),
                                  "speedup_vs_16_single_scans": round(16 * ms_query / ms_multi, 2)}
     # reference point: the same query through stock PyTorch-ROCm operators on the resident store (vector_ops.py:151-188
     # moved to the GPU as is: norms, matrix-vector product, division, top-k)
@@ -135,21 +222,56 @@ def scan_bench(do_cpu):
                                    "what": "rows @ q / (rows.norm(dim=1) * q.norm()) + torch.topk on the same GPU"}
     if do_cpu:
         from oracle.vector_ops_oracle import top_k_cosine_similarity_oracle
-        n_cpu = 200_000
-        sub = rows[:n_cpu].cpu().numpy()
+        idx_gpu, _ = store.search_device(q, SCAN_K)
+        host = rows.cpu().numpy()
         qh = q.cpu().numpy()
-        top_k_cosine_similarity_oracle(qh, sub, SCAN_K)
+        o_idx, _ = top_k_cosine_similarity_oracle(qh, host, SCAN_K)         # warm run (also the parity check)
         best = 1e9
         for _ in range(3):
             t0 = time.perf_counter()
-            top_k_cosine_similarity_oracle(qh, sub, SCAN_K)
+            top_k_cosine_similarity_oracle(qh, host, SCAN_K)
             best = min(best, time.perf_counter() - t0)
-        out["cpu_baseline"] = {"value": round(n_cpu * 4096.0 / best / 1e9, 2), "unit": "GB/s",
+        out["cpu_baseline"] = {"value": round(algo_bytes / best / 1e9, 2), "unit": "GB/s", "s_per_query": round(best, 3),
                                "cores": os.cpu_count(), "kind": "port",
-                               "sample": f"numpy oracle (vector_ops.py:151-188 restated), first {n_cpu} rows of the "
-                                         f"same store, k=32, best of 3 after a warm run; numpy/BLAS default threads"}
+                               "sample": "numpy oracle (vector_ops.py:151-188 restated) on the full 1M x 1024 store, k=32, "
+                                         "best of 3 after a warm run; numpy/BLAS default threads"}
+        out["parity_vs_oracle"] = {"top32_indices_equal": idx_gpu.cpu().tolist() == [int(i) for i in o_idx]}
+        del host
     del rows, store
     torch.cuda.empty_cache()
+    return out
+
+
+def consolidation_bench(do_cpu):
+    """key-frame selection at n = 32 (cfg 1) and n = 3600 (cfg 5, 600 kept), HIP and CPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import recipes
+    from hippomm_amd.consolidation import select_key_frames_device
+    out = {}
+    for n, clusters in ((32, 6), (3600, 600)):
+        feats = recipes.clustered(n, clusters, 0.2, seed=7)
+        dev = torch.from_numpy(feats).cuda()
+        kept = select_key_frames_device(dev)
+        t = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            kept = select_key_frames_device(dev)          # includes the read-back of the count
+            t.append(time.perf_counter() - t0)
+        rec = {"kept": int(kept.numel()), "hip_ms": round(sorted(t)[len(t) // 2] * 1e3, 3)}
+        if do_cpu:
+            from oracle.consolidation_oracle import select_key_frames_oracle
+            want = select_key_frames_oracle(feats, None, 0.9)
+            tc = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                select_key_frames_oracle(feats, None, 0.9)
+                tc.append(time.perf_counter() - t0)
+            rec["cpu_ms"] = round(sorted(tc)[1] * 1e3, 3)
+            rec["kept_equal_oracle"] = kept.cpu().tolist() == want.tolist()
+        out[f"n{n}"] = rec
+    out["what"] = ("hmm_gram_select vs the numpy oracle (hippocampal_memory.py:944-967 restated) on clustered unit rows; "
+                   "hip_ms is the whole call incl. the count read-back, cpu_ms the median of 3")
     return out
 
 
@@ -177,19 +299,37 @@ def joint_bench():
     return out
 
 
-def encoder_cpu_baseline():
+def encoder_cpu_baseline(frames32: torch.Tensor):
+    """the fp32 oracle tower on this host's cores, batch 32 (processing.frame_buffer_size),
+    median of 3 passes."""
     from oracle import imagebind_oracle as ib
-    n = 8
     threads = torch.get_num_threads()
     st = ib.synthetic_state(ib.VISION_HUGE, seed=1234, init="fast")
-    x = torch.randn(n, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    x = frames32.cpu()
     ib.vision_forward(x[:2], st)
-    t0 = time.perf_counter()
-    ib.vision_forward(x, st)
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 2), "unit": "frame-embeddings/s", "cores": threads, "kind": "port",
-            "sample": f"fp32 torch-CPU oracle of the same ViT-H/14 tower (32 blocks), {n} synthetic frames, one timed "
-                      f"pass after a 2-frame warm-up, torch intra-op threads = {threads}"}
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ib.vision_forward(x, st)
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[1]
+    return {"value": round(x.shape[0] / dt, 2), "unit": "frame-embeddings/s", "cores": threads, "kind": "port",
+            "sample": f"fp32 torch-CPU oracle of the same ViT-H/14 tower (32 blocks), batch {x.shape[0]} "
+                      f"(processing.frame_buffer_size), median of 3 passes after a 2-frame warm-up, "
+                      f"torch intra-op threads = {threads}"}
+
+
+def encoder_parity(tower_sd, frames, emb, rows=(0, 1, 127, 128, 255)):
+    """A few rows of the TIMED batch (both halves of the two-stream split) against the fp32 oracle on the same weights."""
+    from oracle import imagebind_oracle as ib
+    st = {k: v.detach().float().cpu() for k, v in tower_sd.items()}
+    rows = [r for r in rows if r < frames.shape[0]]
+    want = ib.vision_forward(frames[rows].cpu(), st)
+    got = emb[rows].cpu()
+    cos = torch.nn.functional.cosine_similarity(got, want, dim=1)
+    return {"rows": rows, "min_cos": round(float(cos.min()), 7), "max_abs_diff": float((got - want).abs().max()),
+            "tolerance": "cos >= 1 - 2e-4 (bf16 operands, fp32 accumulate vs the fp32 oracle)",
+            "ok": bool((1 - cos).max() <= 2e-4)}
 
 
 def torch_rocm_reference():
@@ -197,8 +337,7 @@ def torch_rocm_reference():
     reference runs (ImageBind.forward under no_grad, no autocast, foundation_models.py:116-133), bf16 is the vendor-library
     route.  A reported reference point, never part of the product path."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("torch_vit_probe_lib", os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                                                                                  "tools", "torch_vit_lib.py"))
+    spec = importlib.util.spec_from_file_location("torch_vit_probe_lib", os.path.join(ROOT, "tools", "torch_vit_lib.py"))
     lib = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lib)
     out = {}
@@ -210,18 +349,31 @@ def torch_rocm_reference():
     return out
 
 
+# ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scan", action="store_true")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 10 if args.workload == "cfg2" else 2
+    if args.warmup is None:
+        args.warmup = 3 if args.workload == "cfg2" else 1
+
+    if args.gpus > 1 and "RANK" not in os.environ:          # self-launch; this process never initialises the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong N",
+              file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -229,76 +381,104 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     n_gpus = world
 
     from hippomm_amd.consolidation import select_key_frames_device
     from hippomm_amd.encoder import HipTower, synthetic_state_dict
-    from hippomm_amd.sharding import all_gather_embeddings
+    from hippomm_amd.sharding import all_gather_embeddings, shard_bounds
 
     sd = synthetic_state_dict(("vision",), seed=1234)
     tower = HipTower("vision", sd)
-    del sd
+    extras = rank == 0 and n_gpus == 1 and args.workload == "cfg2"
+    if not (extras and not args.no_cpu_baseline):
+        sd = None
     torch.cuda.empty_cache()
-    frames = torch.randn(FRAMES_PER_GPU, 3, 224, 224, device="cuda",
-                         generator=torch.Generator(device="cuda").manual_seed(rank))
-    emb = torch.empty(FRAMES_PER_GPU, 1024, dtype=torch.float32, device="cuda")
-    counts = [FRAMES_PER_GPU] * world
 
-    def step():
-        tower.forward_into(frames, emb)
-        feats = all_gather_embeddings(emb, counts)
-        return select_key_frames_device(feats)
+    if args.workload == "cfg2":
+        n_total = FRAMES_PER_GPU * world
+        bounds = [(r * FRAMES_PER_GPU, (r + 1) * FRAMES_PER_GPU) for r in range(world)]
+    else:
+        n_total = CFG5_FRAMES
+        bounds = shard_bounds(n_total, world)
+    lo, hi = bounds[rank]
+    counts = [b - a for a, b in bounds]
+    frames = synthetic_frames(lo, hi, "cuda")
+    emb = torch.empty(hi - lo, 1024, dtype=torch.float32, device="cuda")
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        kept = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    def encode(x):
+        for s in range(0, x.shape[0], FRAMES_PER_GPU):
+            tower.forward_into(x[s:s + FRAMES_PER_GPU], emb[s:s + FRAMES_PER_GPU])
+        return emb
+
+    step = make_step(frames, counts, encode, all_gather_embeddings, select_key_frames_device)
+
+    def reduce_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    elapsed, (feats, kept) = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize,
+                                         (dist.barrier if world > 1 else (lambda: None)), reduce_max)
+
+    gather_ms = None
+    if world > 1:                                              # the exchange step alone
+        gather_ms = reduce_max(event_time_ms(lambda: all_gather_embeddings(emb, counts), 20, warmup=3))
 
     if rank == 0:
-        total_frames = n_gpus * FRAMES_PER_GPU * args.steps
-        value = total_frames / elapsed
+        value = n_total * args.steps / elapsed
         ms_step = elapsed / args.steps * 1e3
-        enc_flops = tower.flops(FRAMES_PER_GPU)
-        roof, table = gemm_roofline(FRAMES_PER_GPU * 257)
+        enc_flops = sum(tower.flops(c) for c in counts if c > 0)                   # whole job, nominal
+        enc_flops_exec = sum(tower.flops_executed(c) for c in counts if c > 0)
         line = {
             "metric": "frame-embeddings/sec (ImageBind-huge ViT-H/14 vision tower; scan GB/s under 'scan')",
             "value": round(value, 1), "unit": "frame-embeddings/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg2: ViT-H/14 vision encoder (32 blocks, 257 tokens, D=1280), 256 "
-                                   "synthetic 224x224 frames per GPU per step, random-init weights; step = encode -> "
-                                   "(N>1: RCCL all-gather of embeddings) -> cosine key-frame selection",
-                       "frames_per_gpu": FRAMES_PER_GPU, "sharding": f"frames x{n_gpus}",
-                       "kept_key_frames": int(kept.numel())},
-            "step_tflops": round(enc_flops * args.steps / elapsed / 1e12, 1),
-            "step_mfma_frac": round(enc_flops * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "roofline": roof, "kernels": table,
+            "scaling": "weak" if args.workload == "cfg2" else "strong", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
         }
-        if n_gpus == 1:
-            del tower
+        if args.workload == "cfg2":
+            line["config"] = {"workload": "BASELINE cfg2: ViT-H/14 vision encoder (32 blocks, 257 tokens, D=1280), 256 "
+                                          "synthetic 224x224 frames per GPU per step (scenes of 6 frames), random-init "
+                                          "weights; step = encode -> (N>1: RCCL all-gather of embeddings) -> cosine "
+                                          "key-frame selection",
+                              "frames_per_gpu": FRAMES_PER_GPU, "sharding": f"frames x{n_gpus}",
+                              "kept_key_frames": int(kept.numel()), "of_frames": int(feats.shape[0])}
+        else:
+            from oracle.consolidation_oracle import select_key_frames_oracle
+            want = select_key_frames_oracle(feats.cpu().numpy(), None, 0.9)
+            line["config"] = {"workload": "BASELINE cfg5: 1-hour video at 1 fps = 3600 synthetic frames (600 scenes of 6), "
+                                          "contiguous time shards of ceil(3600/N) frames per rank -> encode -> ONE RCCL "
+                                          "all-gather of the (n_local,1024) fp32 embeddings -> global cosine key-frame "
+                                          "selection on every rank",
+                              "frames_total": n_total, "frames_per_rank": counts, "sharding": f"time shards x{n_gpus}",
+                              "kept_key_frames": int(kept.numel()),
+                              "kept_equal_cpu_oracle_on_gathered_matrix": kept.cpu().tolist() == want.tolist(),
+                              "all_gather_bytes_per_rank": max(counts) * 4096}
+        if gather_ms is not None:
+            line["config"]["all_gather_ms"] = round(gather_ms, 4)
+        line["step_tflops"] = round(enc_flops * args.steps / elapsed / 1e12, 1)
+        line["step_mfma_frac"] = round(enc_flops * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4)
+        line["flops_per_frame_nominal"] = tower.flops(1)
+        line["flops_per_frame_executed"] = round(tower.flops_executed(FRAMES_PER_GPU) / FRAMES_PER_GPU, 1)
+        line["step_tflops_executed"] = round(enc_flops_exec * args.steps / elapsed / 1e12, 1)
+        roof, table = gemm_roofline(FRAMES_PER_GPU * 257)
+        line["roofline"], line["kernels"] = roof, table
+        if extras:
+            if sd is not None:
+                line["parity_vs_oracle"] = encoder_parity(sd, frames, emb)
+                sd = None
+            frames32 = frames[:32].clone()
+            del tower, frames, emb
             torch.cuda.empty_cache()
             if not args.no_scan:
                 line["scan"] = scan_bench(do_cpu=not args.no_cpu_baseline)
                 line["joint_vision_audio"] = joint_bench()
+                line["consolidation"] = consolidation_bench(do_cpu=not args.no_cpu_baseline)
             if not args.no_cpu_baseline:
                 line["torch_rocm_reference"] = torch_rocm_reference()
-                line["cpu_baseline"] = encoder_cpu_baseline()
+                line["cpu_baseline"] = encoder_cpu_baseline(frames32)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -316,11 +316,18 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
 // the CUs of one XCD do not run their epilogue store bursts at the same instant
 HMM_TUNABLE(int, g_gemm_dephase_units, 0)
 HMM_TUNABLE(int, g_gemm_dephase_groups, 4)
-#define HMM_PROBE_ARG , int dephase
-#define HMM_PROBE_VAL , (g_gemm_dephase_groups << 16) | g_gemm_dephase_units
+// in-kernel stamps (s_memrealtime, 100 MHz): per workgroup {start, first K-tile landed, main loop done, stores retired,
+// XCC id, HW id}; written to a buffer of their own that nothing else reads
+unsigned long long* g_gemm_stamps = nullptr;
+extern "C" void hmm_probe_set_gemm_stamps(unsigned long long* p) { g_gemm_stamps = p; }
+#define HMM_PROBE_ARG , int dephase, unsigned long long* stamps
+#define HMM_PROBE_VAL , (g_gemm_dephase_groups << 16) | g_gemm_dephase_units, g_gemm_stamps
+#define HMM_STAMP(slot)                                                                              \
+    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();
 #else
 #define HMM_PROBE_ARG
 #define HMM_PROBE_VAL
+#define HMM_STAMP(slot)
 #endif
 
 template <int EPI>
@@ -339,7 +346,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int m0 = (swz / tiles_n) * 256, n0 = (swz % tiles_n) * 256;
+    HMM_STAMP(0)
 #ifdef HMM_PROBE
+    if (stamps && threadIdx.x == 0) {
+        stamps[(size_t)bid * 8 + 4] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+        stamps[(size_t)bid * 8 + 5] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+    }
     if ((dephase & 0xFFFF) && bid < kNumCU) {
         const int grp = (bid >> 3) % (dephase >> 16);
         for (int i = 0; i < grp * (dephase & 0xFFFF); ++i) __builtin_amdgcn_s_sleep(32);
@@ -414,6 +426,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     HMM_STAGE(W, src_bhi, 1, 1, H_BHI); HMM_STAGE(A, src_ahi, 1, 1, H_AHI);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     HMM_BAR();
+    HMM_STAMP(1)
     if (wm == 1) { HMM_BAR(); }                               // waves 4-7 run one barrier behind
 
 #define HMM_KTILE(t, buf)                                                                 \
@@ -452,7 +465,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 #undef HMM_MFMA_QUAD
 
     // every wave is past its last LDS read and every DMA has landed: the LDS is free
+    HMM_STAMP(2)
     gemm_epilogue_lds<EPI>(acc, bias, Cout, M, N, m0 + wm * 128, n0 + wn * 64, smem + wave * kEpiSlab, lane);
+#ifdef HMM_PROBE
+    if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    HMM_STAMP(3)
+#endif
 }
 
 template <int EPI>

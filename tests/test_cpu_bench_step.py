@@ -1,0 +1,115 @@
+"""CPU: bench.py's launch logic and its step() at world_size 2 on gloo with stand-ins for the two GPU legs.
+
+  * `--gpus N` with N > 1 and no torchrun environment self-launches; with fewer than N GPUs visible it must exit
+    non-zero instead of silently running one rank; a rank whose WORLD_SIZE disagrees with --gpus refuses to run;
+  * the synthetic video is the same whatever the sharding (frame i depends on i only);
+  * make_step / timed_steps (the timed region of bench.py) under gloo: contiguous time shards of BASELINE cfg 5's shape,
+    one all-gather, global selection == single-process selection on the gathered matrix; max-over-ranks timing.
+The encoder leg is stood in by a fixed linear map of the frames, the selection leg by the oracle."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _bench():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    return bench
+
+
+def test_self_launch_refuses_when_gpus_are_missing():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("2+ GPUs visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 3 and "only" in r.stderr and not r.stdout.strip()
+
+
+def test_rank_refuses_a_world_size_that_disagrees_with_gpus():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
+def test_synthetic_video_does_not_depend_on_the_sharding():
+    bench = _bench()
+    whole = bench.synthetic_frames(0, 20, "cpu")
+    assert torch.equal(whole[7:15], bench.synthetic_frames(7, 15, "cpu"))
+    assert torch.equal(whole[12:20], bench.synthetic_frames(12, 20, "cpu"))
+    # frames of one scene are close, frames of different scenes are not
+    flat = whole.flatten(1)
+    flat = flat / flat.norm(dim=1, keepdim=True)
+    sim = flat @ flat.T
+    assert sim[0, 5] > 0.8 and sim[0, 6] < 0.5
+
+
+def _encode_standin(frames):
+    """(n,3,224,224) -> (n,1024): 16x16 average pooling of the pixels + a fixed random projection (deterministic, cheap)."""
+    g = torch.Generator().manual_seed(123)
+    proj = torch.randn(3 * 14 * 14, 1024, generator=g)
+    pooled = torch.nn.functional.avg_pool2d(frames, 16).flatten(1)
+    return pooled @ proj
+
+
+def _worker(rank, world, port, n_frames, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from hippomm_amd import sharding
+        from oracle.consolidation_oracle import select_key_frames_oracle
+
+        bounds = sharding.shard_bounds(n_frames, world)
+        lo, hi = bounds[rank]
+        counts = [b - a for a, b in bounds]
+        frames = bench.synthetic_frames(lo, hi, "cpu")
+
+        def select(f):
+            return torch.from_numpy(select_key_frames_oracle(f.numpy(), None, 0.9).astype(np.int64))
+
+        def reduce_max(x):
+            t = torch.tensor([x], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        step = bench.make_step(frames, counts, _encode_standin, sharding.all_gather_embeddings, select)
+        elapsed, (feats, kept) = bench.timed_steps(step, 2, 1, lambda: None, dist.barrier, reduce_max)
+        full = _encode_standin(bench.synthetic_frames(0, n_frames, "cpu"))
+        want = select_key_frames_oracle(full.numpy(), None, 0.9)
+        q.put((rank, torch.equal(feats, full), kept.tolist() == want.tolist(), len(want), elapsed))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [45, 36])           # ragged (23 + 22) and even shards; scenes straddle the shard boundary
+def test_bench_step_world2_gloo(n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + n_frames) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    times = set()
+    for rank, ok_feats, ok_kept, n_kept, elapsed in results:
+        assert ok_feats, f"rank {rank}: gathered matrix != single-process matrix"
+        assert ok_kept, f"rank {rank}: kept indices != single-process selection"
+        assert 1 < n_kept < n_frames, "the synthetic video must make the selection drop some frames and keep several"
+        times.add(round(elapsed, 9))
+    assert len(times) == 1, "every rank must report the max-over-ranks time"
