@@ -58,11 +58,20 @@ def _sidecar_paths(json_path: Path, modality: str) -> Tuple[Path, Path]:
     return Path(f"{stem}.{modality}.f32.npy"), Path(f"{stem}.sidecar.json")
 
 
+def _as_feature_matrix(a) -> np.ndarray:
+    """One rule for both paths (JSON parse and sidecar): fp32, C-contiguous, and the reference's shape fix-up when a
+    matrix arrives as (1024, N) (:413-417) -- so that an event loads with the same shape whichever path serves it."""
+    a = np.asarray(a)
+    if a.ndim > 1 and a.shape[1] != 1024 and a.shape[0] == 1024:
+        a = a.T
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
 def _write_sidecars(json_path: Path, features: Mapping[str, np.ndarray]) -> None:
     st = json_path.stat()
     shapes = {}
     for modality, arr in features.items():
-        a = np.ascontiguousarray(arr, dtype=np.float32)
+        a = _as_feature_matrix(arr)
         npy, _ = _sidecar_paths(json_path, modality)
         tmp = npy.with_suffix(".tmp.npy")
         np.save(tmp, a)
@@ -117,12 +126,7 @@ def parse_event_features(json_path) -> Tuple[Dict[str, np.ndarray], Dict[str, np
                     times[modality] = np.array(d["times"])
             else:
                 feats[modality] = np.array(d)
-    out = {}
-    for modality, a in feats.items():
-        if a.ndim > 1 and a.shape[1] != 1024 and a.shape[0] == 1024:      # the reference's transpose fix-up (:413-417)
-            a = a.T
-        out[modality] = np.ascontiguousarray(a, dtype=np.float32)
-    return out, times
+    return {modality: _as_feature_matrix(a) for modality, a in feats.items()}, times
 
 
 def load_event_features(json_path, use_sidecar: bool = True, write_sidecar: bool = True,
@@ -133,9 +137,14 @@ def load_event_features(json_path, use_sidecar: bool = True, write_sidecar: bool
         m = _fresh_manifest(json_path)
         if m is not None:
             try:
-                return {mod: np.load(_sidecar_paths(json_path, mod)[0], mmap_mode="r" if mmap else None)
-                        for mod in m["modalities"]}
-            except OSError:
+                out = {}
+                for mod, shape in m["modalities"].items():
+                    a = np.load(_sidecar_paths(json_path, mod)[0], mmap_mode="r" if mmap else None)
+                    if a.dtype != np.float32 or list(a.shape) != list(shape):
+                        raise ValueError(f"sidecar of {mod!r} is {a.dtype}{a.shape}, manifest says float32{tuple(shape)}")
+                    out[mod] = a
+                return out
+            except (OSError, ValueError):            # missing, truncated or foreign .npy: fall back to the JSON
                 pass
     feats, _ = parse_event_features(json_path)
     if write_sidecar:
@@ -166,6 +175,8 @@ def build_event_store(memory_store_dir, modality: str = "vision", device=None):
     for event_id, path in iter_event_files(memory_store_dir):
         feats = load_event_features(path)
         a = feats.get(modality)
+        if a is not None and a.ndim == 1 and a.shape[0] == 1024:
+            a = a.reshape(1, 1024)                   # top_k_cosine_similarity treats a 1-D feature as one row (vector_ops.py:173-174)
         if a is None or a.ndim != 2 or a.shape[1] != 1024:
             a = np.zeros((0, 1024), np.float32)
         ids.append(event_id)

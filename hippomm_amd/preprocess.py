@@ -187,6 +187,40 @@ def read_wav(path: str) -> Tuple[np.ndarray, int]:
     return np.ascontiguousarray(x.T), int(rate)
 
 
+@lru_cache(maxsize=8)
+def _resample_kernel(orig: int, new: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """Polyphase windowed-sinc kernels of torchaudio.functional.resample (sinc_interp_hann, its defaults), which
+    upstream's load_and_transform_audio_data applies when a file is not at 16 kHz [upstream, recalled:
+    torchaudio/functional/functional.py _get_sinc_resample_kernel].  orig / new are already divided by their gcd.
+    -> (kernels (new, 1, 2*width + orig) fp32, width)."""
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base_freq).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    scale = base_freq / orig
+    kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t) * window * scale
+    return kernels.to(torch.float32), width
+
+
+def resample_waveform(waveform: torch.Tensor, orig_freq: int, new_freq: int = AUDIO_SAMPLE_RATE) -> torch.Tensor:
+    """(channels, n) fp32 at orig_freq -> (channels, ceil(n * new / orig)) at new_freq; runs where `waveform` lives.
+    One strided conv1d against `new` phase kernels (polyphase form), as torchaudio's _apply_sinc_resample_kernel."""
+    if orig_freq == new_freq:
+        return waveform
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    kernels, width = _resample_kernel(orig, new)
+    x = waveform.to(torch.float32)
+    length = x.shape[-1]
+    x = torch.nn.functional.pad(x, (width, width + orig))
+    y = torch.nn.functional.conv1d(x[:, None], kernels.to(x.device), stride=orig)      # (channels, new, frames)
+    y = y.transpose(1, 2).reshape(x.shape[0], -1)
+    return y[..., : math.ceil(new * length / orig)]
+
+
 @lru_cache(maxsize=4)
 def _fbank_tables(device_str: str) -> Tuple[torch.Tensor, torch.Tensor]:
     """Hann window (400) and kaldi mel banks (128, 257) in the float32 torch CPU arithmetic torchaudio uses
@@ -222,19 +256,20 @@ def melspec_clips_device(clips: torch.Tensor, mean: float = AUDIO_MEAN, std: flo
 
 
 def transform_waveforms_device(waveforms: Sequence, device, sample_rate: int = AUDIO_SAMPLE_RATE) -> torch.Tensor:
-    """waveforms: per file a (channels, n) or (n,) float array / tensor at 16 kHz -> (B,3,1,128,204) fp32 on `device`.
-    Channel 0 is analysed (kaldi.fbank's default channel).  Upstream's `waveform -= waveform.mean()` runs over all
+    """waveforms: per file a (channels, n) or (n,) float array / tensor -> (B,3,1,128,204) fp32 on `device`.  Input at
+    another rate than 16 kHz is resampled first (torchaudio's windowed-sinc polyphase filter, resample_waveform), as
+    upstream does.  Channel 0 is analysed (kaldi.fbank's default channel).  Upstream's `waveform -= waveform.mean()` runs over all
     channels, but any constant offset is removed again per frame (remove_dc_offset), so for multi-channel input the
     result differs from the mono rule only in rounding; the reference always writes mono (:1204-1207, ffmpeg -ac 1)."""
-    if sample_rate != AUDIO_SAMPLE_RATE:
-        raise ValueError(f"audio must be sampled at {AUDIO_SAMPLE_RATE} Hz (got {sample_rate}); the reference extracts "
-                         "its audio with ffmpeg -ar 16000, resampling is not built")
+    rates = list(sample_rate) if isinstance(sample_rate, (list, tuple)) else [sample_rate] * len(waveforms)
     groups = {}                                      # clip length -> [(file index, clip index, samples)]
     for fi, w in enumerate(waveforms):
         w = torch.as_tensor(np.asarray(w) if not isinstance(w, torch.Tensor) else w, dtype=torch.float32)
         if w.dim() == 1:
             w = w[None]
-        for ci, (s, e) in enumerate(audio_clip_bounds(w.shape[1], sample_rate)):
+        if rates[fi] != AUDIO_SAMPLE_RATE:
+            w = resample_waveform(w[:1].to(device), int(rates[fi]), AUDIO_SAMPLE_RATE).cpu()
+        for ci, (s, e) in enumerate(audio_clip_bounds(w.shape[1], AUDIO_SAMPLE_RATE)):
             groups.setdefault(e - s, []).append((fi, ci, w[0, s:e]))
     out = torch.empty(len(waveforms), AUDIO_CLIPS_PER_VIDEO, 1, AUDIO_MEL_BINS, AUDIO_TARGET_LENGTH,
                       dtype=torch.float32, device=device)
@@ -248,11 +283,11 @@ def transform_waveforms_device(waveforms: Sequence, device, sample_rate: int = A
 
 
 def load_and_transform_audio_data_device(audio_paths: Sequence[str], device) -> torch.Tensor:
-    """Drop-in for imagebind.data.load_and_transform_audio_data(audio_paths, device) on 16 kHz wav files."""
-    waves = []
+    """Drop-in for imagebind.data.load_and_transform_audio_data(audio_paths, device) on wav files (any sample rate;
+    the reference itself writes 16 kHz, hippocampal_memory.py:1219, :1386-1394)."""
+    waves, rates = [], []
     for p in audio_paths:
         x, rate = read_wav(p)
-        if rate != AUDIO_SAMPLE_RATE:
-            raise ValueError(f"{p}: sample rate {rate} Hz, expected {AUDIO_SAMPLE_RATE} (resampling is not built)")
         waves.append(x)
-    return transform_waveforms_device(waves, device)
+        rates.append(rate)
+    return transform_waveforms_device(waves, device, rates)

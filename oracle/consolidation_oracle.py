@@ -94,3 +94,12 @@ def select_key_frames_exact(features: np.ndarray,
         with np.errstate(invalid="ignore"):
             blocked |= ~(gram[i] < thr)
     return np.array(kept, dtype=np.int64)
+
+
+def pair_similarities(features: np.ndarray, n_pairs: int) -> np.ndarray:
+    """float64 cosine of the fp32-normalised rows (2j, 2j+1), j < n_pairs, under the HIP definition (before the final
+    rounding to fp32): how far the in-band fixtures' pairs really sit from the threshold."""
+    f32 = np.ascontiguousarray(features, dtype=np.float32)
+    norm = np.sqrt(np.sum(f32.astype(np.float64) ** 2, axis=1)).astype(np.float32)
+    unit = (f32 / norm[:, None]).astype(np.float32).astype(np.float64)
+    return np.array([unit[2 * j].dot(unit[2 * j + 1]) for j in range(n_pairs)])

@@ -111,12 +111,31 @@ def main():
             "kept": [int(i) for i in kept], "kept_dtype": str(kept.dtype),
             "min_evaluated_margin": (None if not np.isfinite(margin) else margin),
         }
+    # in-band fixtures: the reference's answer here depends on this host's BLAS summation order -> informational
+    from oracle.consolidation_oracle import select_key_frames_exact, pair_similarities
+    sel["inband_cases"] = {}
+    for name in recipes.SELECT_INBAND_CASES:
+        f, t = recipes.select_case(name)
+        kept = select_ref(None, f, t)
+        exact = select_key_frames_exact(f)
+        n_pairs = 4 if name == "n24_inband_1e6" else 7
+        sel["inband_cases"][name] = {
+            "n": int(f.shape[0]), "threshold": 0.9, "input_sha256": recipes.sha256(f),
+            "kept_reference_on_this_host": [int(i) for i in kept],
+            "kept_exact_definition": [int(i) for i in exact],
+            "informational": "BLAS-order dependent: the reference's kept list is what numpy %s on %s returned" % (
+                np.__version__, env["machine"]),
+            "pair_minus_threshold_fp64": [float(x) for x in pair_similarities(f, n_pairs) - float(np.float32(0.9))],
+        }
     (HERE / "select_golden.json").write_text(json.dumps(sel, indent=1))
     # memory_store event JSON, exactly as save_theta_event writes it (hippocampal_memory.py:110-133, :331-335)
     from hippomm.core.hippocampal_memory import ThetaEvent
     ev = ThetaEvent(**recipes.event_case())
     (HERE / "event_golden.json").write_text(json.dumps(ev.to_dict(), indent=2))
     print("event golden:", (HERE / "event_golden.json").stat().st_size, "bytes")
+    for name, c in sel["inband_cases"].items():
+        print(f"inband {name:20s} ref={c['kept_reference_on_this_host'][:12]} exact={c['kept_exact_definition'][:12]} "
+              f"pairs-thr={['%.1e' % x for x in c['pair_minus_threshold_fp64']]}")
     for name, c in sel["cases"].items():
         print(f"select {name:24s} n={c['n']:5d} kept={len(c['kept']):4d} margin={c['min_evaluated_margin']}")
     for name, c in scan["cases"].items():

@@ -103,6 +103,36 @@ def test_full_transform_shape_and_normalisation():
         fb.load_and_transform_audio(w, 44100)
 
 
+@pytest.mark.parametrize("orig", [44100, 48000, 22050, 8000])
+def test_resample_to_16k(orig):
+    """resample_waveform restates torchaudio.functional.resample (windowed sinc, Hann, lowpass_filter_width 6, rolloff
+    0.99) [upstream, recalled; torchaudio is not in this image: unpinned].  Checked here by what the filter must do:
+    length rule ceil(n * new / orig), a tone below the new Nyquist keeps amplitude and frequency, a tone above it is
+    removed, and scipy's polyphase resampler (an independent design) agrees on band-limited input."""
+    from scipy.signal import resample_poly
+    from hippomm_amd.preprocess import resample_waveform
+    n = orig * 2
+    t = np.arange(n) / orig
+    low = np.sin(2 * np.pi * 1000.0 * t).astype(np.float32)
+    y = resample_waveform(torch.from_numpy(low)[None], orig, 16000)[0].numpy()
+    assert y.shape[0] == int(np.ceil(n * 16000 / orig))
+    tt = np.arange(y.shape[0]) / 16000.0
+    mid = slice(200, -200)
+    assert np.abs(y[mid] - np.sin(2 * np.pi * 1000.0 * tt)[mid]).max() < 2e-3
+    if orig > 16000:
+        # 2.5 kHz above the new Nyquist: past the transition band of the 6-zero-crossing Hann-windowed sinc (-44 dB)
+        high = np.sin(2 * np.pi * (0.5 * 16000 + 2500.0) * t).astype(np.float32)
+        assert np.abs(resample_waveform(torch.from_numpy(high)[None], orig, 16000)[0].numpy()[mid]).max() < 1e-2
+    g = np.gcd(orig, 16000)
+    rng = np.random.default_rng(orig)
+    band = np.convolve(rng.standard_normal(n), np.hanning(64) / 32.0, mode="same").astype(np.float32)   # low-passed noise
+    ours = resample_waveform(torch.from_numpy(band)[None], orig, 16000)[0].numpy()
+    ref = resample_poly(band.astype(np.float64), 16000 // g, orig // g)[: ours.shape[0]]
+    assert np.abs(ours[mid] - ref[mid]).max() < 0.02 * np.abs(ref).max()
+    # identity when nothing has to change
+    assert resample_waveform(torch.from_numpy(low)[None], 16000, 16000).shape[1] == n
+
+
 def test_read_wav_round_trip(tmp_path):
     from scipy.io import wavfile
     from hippomm_amd.preprocess import read_wav
@@ -272,6 +302,14 @@ def test_imagebind_load_data_accepts_wav_paths(tmp_path):
     assert_melspec_close(data["audio"][0].cpu(), torch.from_numpy(w)[None], "load_data wav path")
     feats = model.extract_features({"audio": [str(tmp_path / "seg.wav")]}, ["audio"])["audio"]
     assert feats.shape == (1, 1024) and torch.isfinite(feats).all()
-    # wrong sample rate: logged and skipped like any per-modality failure (:110-112)
-    wavfile.write(tmp_path / "bad.wav", 44100, w)
+    # another sample rate: resampled to 16 kHz first, as upstream's load_and_transform_audio_data does
+    from hippomm_amd.preprocess import resample_waveform
+    w44 = (torch.randn(44100 * 4, generator=g) * 0.2).numpy().astype(np.float32)
+    wavfile.write(tmp_path / "cd.wav", 44100, w44)
+    data44 = model.load_data({"audio": [str(tmp_path / "cd.wav")]}, ["audio"])
+    assert data44["audio"].shape == (1, 3, 1, 128, 204)
+    assert_melspec_close(data44["audio"][0].cpu(), resample_waveform(torch.from_numpy(w44)[None], 44100, 16000),
+                         "load_data 44.1 kHz wav path")
+    # an unreadable file: logged and skipped like any per-modality failure (:110-112)
+    (tmp_path / "bad.wav").write_bytes(b"not a wav file")
     assert "audio" not in model.load_data({"audio": [str(tmp_path / "bad.wav")]}, ["audio"])

@@ -67,6 +67,27 @@ def test_old_event_format_and_transposed_features(tmp_path):
     assert times["vision"].tolist() == [0.0, 1.0, 2.5]
 
 
+def test_sidecar_and_json_paths_agree_on_shape_and_survive_a_broken_sidecar(tmp_path):
+    """save_event applies the same fix-ups as the JSON reader (a (1024,N) matrix is stored as (N,1024) either way), the
+    loaded sidecar is checked against the manifest, and a truncated / foreign .npy falls back to the JSON."""
+    case = recipes.event_case()
+    v = case["features"]["vision"]
+    case["features"]["vision"] = np.ascontiguousarray(np.tile(v, (2, 1)).T)          # (1024, 6): transposed on purpose
+    p = es.save_event(case, tmp_path / "ev" / "t_0.json")
+    fast = es.load_event_features(p)
+    slow, _ = es.parse_event_features(p)
+    assert fast["vision"].shape == slow["vision"].shape == (6, 1024)
+    np.testing.assert_array_equal(fast["vision"], slow["vision"])
+    npy = tmp_path / "ev" / "t_0.vision.f32.npy"
+    good = npy.read_bytes()
+    npy.write_bytes(good[: len(good) // 2])                                           # truncated: np.load raises ValueError
+    np.testing.assert_array_equal(es.load_event_features(p, write_sidecar=False)["vision"], slow["vision"])
+    np.save(npy, np.zeros((5, 1024), np.float64))                                     # foreign dtype / shape
+    np.testing.assert_array_equal(es.load_event_features(p, write_sidecar=False)["vision"], slow["vision"])
+    np.testing.assert_array_equal(es.load_event_features(p)["vision"], slow["vision"])   # repairs the cache
+    assert np.load(npy).dtype == np.float32 and np.load(npy).shape == (6, 1024)
+
+
 def test_index_iteration(tmp_path):
     case = recipes.event_case()
     base = tmp_path / "memory_store"

@@ -66,7 +66,7 @@ def test_device_preprocess_is_bit_identical_to_the_host_path(h, w):
 
 @pytest.mark.gpu
 def test_image_files_mixed_sizes(tmp_path):
-    from hippomm_amd.encoder import load_and_transform_vision_data
+    from host_vision_pipeline import load_and_transform_vision_data
     rng = np.random.default_rng(5)
     paths = []
     for i, (h, w) in enumerate([(300, 400), (300, 400), (256, 256), (400, 300)]):
