@@ -7,10 +7,19 @@
 // The Q x rows similarity block is a GEMM on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: store rows are the
 // A operand, queries the B operand, IEEE fp32 products and sums -- no precision is given up): per row 2 x 1024 x 16
 // FLOP, ~50 TFLOP/s at the HBM-bound row rate against a ~157 TFLOP/s fp32 matrix peak, so the kernel stays on the
-// memory roofline.  Workgroup = 4 waves; a wave owns 64 rows (four 16-row tiles) per iteration and reads them with
-// 2 x 16 B per lane such that the four lanes of a row cover one whole 128-B line per step, three steps in flight.
-// Queries live in LDS (row stride padded by 16 B against bank conflicts) and are re-read per step (b128).
+// memory roofline.
 //
+// Data movement (round 2; round 1 read 16 rows x 64 B per load instruction straight into registers and stopped at
+// 5.0 TB/s of loads):
+//   * the store is streamed by LDS-DMA in 512-B row pieces: one global_load_lds_dwordx4 fetches 2 rows x 512 B
+//     (whole 128-B lines, two contiguous runs), a wave keeps a private ring of 3 slices (16 rows x 128 floats, 8 KiB)
+//     with two slices always in flight behind a counted vmcnt -- no registers are spent on loads;
+//   * the 16 queries live in REGISTERS: the B operand of lane (q, g) is q[.][16 j + 4 g + s], 256 values per lane for
+//     the whole kernel (one wave per SIMD, 512 registers), so the main loop reads nothing but the A fragments from
+//     LDS: one ds_read_b128 per four MFMAs;
+//   * LDS image of a slice: piece i (rows 2i, 2i+1) at i x 1056 B, inside it 16-B unit 2c + (row & 1) holds chunk c of
+//     the row -- the source address of each DMA lane is permuted accordingly.  A fragment read (16 rows, same chunk)
+//     then touches 16 different 16-B bank slots: conflict-free.
 // Selection is fused: every query has a candidate list of order keys in LDS and a threshold = its current k-th best;
 // only keys above the threshold are appended (LDS atomic), lists are sorted down to k when they could overflow and at
 // the end, and each workgroup leaves its best k keys per query.  A second kernel (one workgroup per query) finishes
@@ -21,21 +30,27 @@
 namespace hmm {
 
 constexpr int kMQ = 16;                 // queries per pass
-constexpr int kMWaves = 4;              // one wave per SIMD: 512 registers each (3 steps x 4 tiles of loads in flight)
-constexpr int kMTiles = 4;              // 16-row tiles per wave
-constexpr int kMRows = kMWaves * kMTiles * 16;    // 256 rows per workgroup iteration
-constexpr int kMCap = 512;              // candidate keys per query (>= k + kMRows)
+constexpr int kMWaves = 4;              // one wave per SIMD: 512 registers each (256 of them hold the queries)
+constexpr int kMTileRows = 16;          // rows per wave per round (one MFMA tile)
+constexpr int kMRows = kMWaves * kMTileRows;      // rows per workgroup per round
+constexpr int kMSlices = 8;             // K slices per tile: 128 floats each
+constexpr int kMPiece = 1056;           // LDS bytes per DMA piece: 2 rows x 512 B + 32 B (bank rotation between pieces)
+constexpr int kMSliceBytes = 8 * kMPiece;
+constexpr int kMRing = 3;               // slices per wave: one being read, two in flight
+constexpr int kMCap = 256;              // candidate keys per query and workgroup (>= k + kMRows, power of two)
 constexpr int kMMaxK = 64;              // k*k <= 4096 for the one-kernel finish
-constexpr int kMQStride = 1024 + 4;     // floats per query row in LDS
 constexpr int kMMaxBlocks = 2048;
 
 struct MultiLds {
-    float q[kMQ * kMQStride];           // 65792 B
-    uint64_t keys[kMQ][kMCap];          // 65536 B
+    char ring[kMWaves][kMRing][kMSliceBytes];     // 101376 B
+    uint64_t keys[kMQ][kMCap];                     //  32768 B
     uint64_t tau[kMQ];
-    float qlen[kMQ];
     int cnt[kMQ];
+    int need;                                      // workgroup-uniform "sort now" flag (written by wave 0 between barriers)
 };
+
+#define HMM_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define HMM_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
 // Descending bitonic sort, by ONE wave, of the first n2 (power of two, <= kMCap) keys of NL lists at once: the lists'
 // compare-exchange steps are independent, so walking them in lockstep overlaps their LDS round trips (a single
@@ -61,135 +76,147 @@ __device__ __forceinline__ void wave_bitonic_desc(uint64_t* (&s)[NL], int n2, in
     }
 }
 
+// A raw workgroup barrier that leaves LDS-DMA in flight (__syncthreads() would drain vmcnt to 0).
+__device__ __forceinline__ void multi_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 __global__ __launch_bounds__(kMWaves * 64) void scan_multi_kernel(const float* __restrict__ store, int64_t n_rows,
                                                                   const float* __restrict__ queries, int n_q, int k,
-                                                                  uint64_t* __restrict__ out, int g_multi_rot) {
+                                                                  uint64_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     MultiLds& L = *reinterpret_cast<MultiLds*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
 
-    // queries -> LDS (zero rows past n_q), their lengths, empty lists
-    for (int i = tid; i < kMQ * 256; i += kMWaves * 64) {
-        const int qi = i >> 8, c = i & 255;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (qi < n_q) v = reinterpret_cast<const float4*>(queries)[(size_t)qi * 256 + c];
-        *reinterpret_cast<float4*>(&L.q[qi * kMQStride + 4 * c]) = v;
+    // B operand: lane (q = r16, g) holds q[128 s + 16 j + 4 g + 0..3] for every slice s and step j (zero rows past n_q).
+    // The queries pass through LDS once (coalesced 16-B loads, rows padded by 16 B against bank conflicts; the ring is
+    // still idle): fetching the 64 fragments per lane straight from global memory serialises 64 L2 round trips.
+    {
+        constexpr int QS = 1024 + 4;                              // floats per staged query row
+        float* qs = reinterpret_cast<float*>(&L.ring[0][0][0]);   // 16 x 4112 B = 65792 B of the 101376-B ring
+        for (int i = tid; i < kMQ * 256; i += kMWaves * 64) {
+            const int qi = i >> 8, c = i & 255;
+            const int src_row = qi < n_q ? qi : n_q - 1;          // clamped row + select: no branch around the load
+            f32x4 v = *reinterpret_cast<const f32x4*>(queries + (size_t)src_row * 1024 + 4 * c);
+            if (qi >= n_q) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(qs + qi * QS + 4 * c) = v;
+        }
+        __syncthreads();
     }
+    f32x4 bq[kMSlices][8];
+    float qss = 0.f;
+    {
+        constexpr int QS = 1024 + 4;
+        const float* qs = reinterpret_cast<const float*>(&L.ring[0][0][0]) + r16 * QS + 4 * g;
+#pragma unroll
+        for (int sl = 0; sl < kMSlices; ++sl)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(qs + 128 * sl + 16 * j);
+                bq[sl][j] = v;
+                qss = fmaf(v[0], v[0], qss); qss = fmaf(v[1], v[1], qss); qss = fmaf(v[2], v[2], qss); qss = fmaf(v[3], v[3], qss);
+            }
+    }
+    qss += __shfl_xor(qss, 16, 64);
+    qss += __shfl_xor(qss, 32, 64);
+    const float my_qlen = sqrtf(qss);                             // |query r16|, in all four lanes that hold a part of it
     if (tid < kMQ) { L.cnt[tid] = 0; L.tau[tid] = 0ull; }
-    __syncthreads();
-    for (int qi = wave; qi < kMQ; qi += kMWaves) {
-        float s = 0.f;
-        for (int c = lane; c < 1024; c += 64) { const float v = L.q[qi * kMQStride + c]; s = fmaf(v, v, s); }
-        s = wave_sum(s);
-        if (lane == 0) L.qlen[qi] = sqrtf(s);
-    }
-    __syncthreads();
-    const float my_qlen = L.qlen[r16];
-    const float* qb = &L.q[r16 * kMQStride + 8 * g];            // + 32*i (+4): this lane's B fragments
+    if (tid == 0) L.need = 0;
+    __syncthreads();                                              // fragments are in registers: the ring may be overwritten
 
-    const int64_t n_chunks = (n_rows + kMRows - 1) / kMRows;
-    constexpr int STAGES = 4;                                     // register ring: 3 steps of loads in flight (8 measured slower)
-    f32x4 a[STAGES][kMTiles][2];
-    const float* a_ptr[kMTiles];
-    int rot = 0;
-    // A operand: lane (r16, g) reads row r16 of each tile, columns 32*i + 8*g .. +7.  Every wave walks K from a different
-    // starting step: the 16 rows of a tile are 4 KiB apart, so at any moment a wave asks for the same 128-B column of 16
-    // rows; rotating the walk spreads concurrent waves over the columns.
-    auto begin_chunk = [&](int64_t chunk) {                       // row pointers + the first STAGES-1 steps of loads
-        const int64_t row0 = chunk * kMRows + wave * (kMTiles * 16);
+    const int64_t n_tiles = (n_rows + kMTileRows - 1) / kMTileRows;
+    const int64_t n_waves = (int64_t)gridDim.x * kMWaves;
+    const int64_t wave_gid = (int64_t)blockIdx.x * kMWaves + wave;
+    const int64_t n_rounds = (n_tiles + n_waves - 1) / n_waves;   // same for every wave of the grid
+
+    // DMA source of lane l for piece i of (tile, slice): row 16 tile + 2 i + (l & 1), 16-B chunk 32 slice + (l >> 1)
+    const int src_lane = (lane & 1) * 1024 + (lane >> 1) * 4;     // floats
+    char* my_ring = L.ring[wave][0];
+    auto issue_slice = [&](int64_t tile, int sl, int slot) {
+        int64_t row0 = tile * kMTileRows;
 #pragma unroll
-        for (int t = 0; t < kMTiles; ++t) {
-            int64_t r = row0 + 16 * t + r16;
-            r = r < n_rows ? r : n_rows - 1;
-            a_ptr[t] = store + r * 1024 + 8 * g;
+        for (int i = 0; i < 8; ++i) {
+            int64_t row = row0 + 2 * i + (lane & 1);
+            row = row < n_rows ? row : n_rows - 1;                // clamp: rows past the end are masked at selection
+            const float* src = store + row * 1024 + 32 * sl + (lane >> 1) * 4;
+            __builtin_amdgcn_global_load_lds(HMM_GLB_PTR(src), HMM_LDS_PTR(my_ring + slot * kMSliceBytes + i * kMPiece),
+                                             16, 0, 0);
         }
-        rot = (g_multi_rot & 1) ? (int)((chunk * kMWaves + wave) * 5) & 31 : 0;
-#pragma unroll
-        for (int s = 0; s < STAGES - 1; ++s)
-#pragma unroll
-            for (int t = 0; t < kMTiles; ++t) {
-                a[s][t][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_ptr[t] + 32 * ((s + rot) & 31)));
-                a[s][t][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_ptr[t] + 32 * ((s + rot) & 31) + 4));
-            }
     };
-    if ((int64_t)blockIdx.x < n_chunks) begin_chunk(blockIdx.x);
-    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const int64_t row0 = chunk * kMRows + wave * (kMTiles * 16);     // this wave's 64 rows
-        // the query fragments are invariant across chunks: without this opaque zero the compiler hoists all 64 LDS
-        // reads (256 registers) out of the chunk loop and spills
-        int zv;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(zv));
-        const float* qbi = qb + zv;
-        const bool abl_nomfma = g_multi_rot & 2, abl_noselect = g_multi_rot & 4;      // timing ablations (wrong results)
-        f32x4 acc[kMTiles];
-        float ss[kMTiles];
+    (void)src_lane;
+    // A fragment of lane (r16, g), step j: chunk c = 4 j + g of row r16 -> unit 2 c + (r16 & 1) of piece r16 >> 1
+    const int a_lane = (r16 >> 1) * kMPiece + (r16 & 1) * 16 + g * 32;
+
+    // flattened (round, slice) sequence n = 8 round + slice; slot n % 3; slices n + 1, n + 2 are in flight while n is read
+    auto tile_of = [&](int64_t round) { return wave_gid + round * n_waves; };
+    issue_slice(tile_of(0), 0, 0);
+    issue_slice(tile_of(0), 1, 1);
+    int slot = 0;                                                 // slot of the slice being read
+    for (int64_t round = 0; round < n_rounds; ++round) {
+        const int64_t tile = tile_of(round);
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        float ss = 0.f;
 #pragma unroll
-        for (int t = 0; t < kMTiles; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ss[t] = 0.f; }
-        const int rot_cur = rot;
-#pragma unroll 4
-        for (int i = 0; i < 32; ++i) {                            // unrolled by STAGES: ring slots are compile-time
-            const int cur = i % STAGES, nxt = (i + STAGES - 1) % STAGES;
-            if (i + STAGES - 1 < 32) {
+        for (int sl = 0; sl < kMSlices; ++sl) {
+            // refill the slot read in the previous step (its ds_reads were waited for before that step's MFMAs)
+            const int nslot = slot == 0 ? 2 : slot - 1;           // (slot + 2) % 3
+            if (sl + 2 < kMSlices) issue_slice(tile, sl + 2, nslot);
+            else                   issue_slice(tile_of(round + 1), sl + 2 - kMSlices, nslot);   // next round (clamped past the end)
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // slice n has landed; n + 1, n + 2 stay in flight
+            __builtin_amdgcn_sched_barrier(0);
+            const char* ap = my_ring + slot * kMSliceBytes + a_lane;
+            f32x4 x[8];
 #pragma unroll
-                for (int t = 0; t < kMTiles; ++t) {
-                    a[nxt][t][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_ptr[t] + 32 * ((i + STAGES - 1 + rot_cur) & 31)));
-                    a[nxt][t][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_ptr[t] + 32 * ((i + STAGES - 1 + rot_cur) & 31) + 4));
-                }
+            for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const f32x4*>(ap + j * 128);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 b = bq[sl][j];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][0], b[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][1], b[1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][2], b[2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][3], b[3], acc1, 0, 0, 0);
+                ss = fmaf(x[j][0], x[j][0], ss); ss = fmaf(x[j][1], x[j][1], ss);
+                ss = fmaf(x[j][2], x[j][2], ss); ss = fmaf(x[j][3], x[j][3], ss);
             }
-            __builtin_amdgcn_sched_barrier(0);                     // keep the prefetch depth at STAGES - 1 steps
-            const float4 b0 = *reinterpret_cast<const float4*>(qbi + 32 * ((i + rot_cur) & 31));
-            const float4 b1 = *reinterpret_cast<const float4*>(qbi + 32 * ((i + rot_cur) & 31) + 4);
-#pragma unroll
-            for (int t = 0; t < kMTiles; ++t) {
-                const f32x4 x0v = a[cur][t][0], x1v = a[cur][t][1];
-                const float4 x0 = make_float4(x0v[0], x0v[1], x0v[2], x0v[3]), x1 = make_float4(x1v[0], x1v[1], x1v[2], x1v[3]);
-                if (abl_nomfma) { ss[t] += (x0.x + x0.y) + (x1.z + x1.w); continue; }
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, b0.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, b0.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, b0.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, b0.w, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, b1.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, b1.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, b1.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, b1.w, acc[t], 0, 0, 0);
-                ss[t] = fmaf(x0.x, x0.x, ss[t]); ss[t] = fmaf(x0.y, x0.y, ss[t]);
-                ss[t] = fmaf(x0.z, x0.z, ss[t]); ss[t] = fmaf(x0.w, x0.w, ss[t]);
-                ss[t] = fmaf(x1.x, x1.x, ss[t]); ss[t] = fmaf(x1.y, x1.y, ss[t]);
-                ss[t] = fmaf(x1.z, x1.z, ss[t]); ss[t] = fmaf(x1.w, x1.w, ss[t]);
-            }
+            slot = slot == 2 ? 0 : slot + 1;
         }
-        // the next chunk's first loads fly during the selection below (the ring is free again)
-        if (chunk + gridDim.x < n_chunks) begin_chunk(chunk + gridDim.x);
         // row norms: the four lanes (r16, g = 0..3) of a row hold its partial sums
-#pragma unroll
-        for (int t = 0; t < kMTiles; ++t) {
-            float s = ss[t];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            const float norm = sqrtf(s);                          // lanes 0..15 (and copies): row 16*t + lane%16
-            // D layout: this lane holds query r16, rows 4*g + j of the tile
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float norm = sqrtf(ss);                             // row r16 of the tile
+        const f32x4 acc = acc0 + acc1;                            // D layout: query r16, rows 4 g + j
+        if (tile < n_tiles) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float rn = __shfl(norm, 4 * g + j, 64);
-                const int64_t row = row0 + 16 * t + 4 * g + j;
-                const float sim = acc[t][j] / (rn * my_qlen);
+                const int64_t row = tile * kMTileRows + 4 * g + j;
+                const float sim = acc[j] / (rn * my_qlen);
                 const uint64_t key = ((uint64_t)order_bits(sim) << 32) | (uint64_t)(uint32_t)row;
-                if (r16 < n_q && row < n_rows && key > L.tau[r16] && !abl_noselect) {
+                if (r16 < n_q && row < n_rows && key > L.tau[r16]) {
                     const int pos = atomicAdd(&L.cnt[r16], 1);
                     L.keys[r16][pos] = key;
                 }
             }
         }
-        __syncthreads();
-        // Sort the lists down to k: at the end, whenever one could overflow in the next iteration, and once after the very
-        // first iteration -- that sets the thresholds early, so that from the second iteration on only rows that beat the
-        // current k-th best are appended at all.
-        bool need = chunk + gridDim.x >= n_chunks || chunk == (int64_t)blockIdx.x;
-#pragma unroll
-        for (int qi = 0; qi < kMQ; ++qi) need |= L.cnt[qi] > kMCap - kMRows;
-        if (need) {                                               // workgroup-uniform
+        // Sort the lists down to k: at the end, whenever one could overflow in the next round, and once after the very
+        // first round -- that sets the thresholds early, so that from the second round on only rows that beat the
+        // current k-th best are appended at all.  The decision is taken by ONE wave between two barriers and read by
+        // the others after the second one: it is workgroup-uniform by construction (no wave can append again before
+        // every wave has read the flag, because the flag is reset only behind the third barrier).
+        multi_barrier();                                          // every append of this round is visible
+        if (wave == 0) {
+            bool need = round + 1 >= n_rounds || round == 0;
+            if (lane < kMQ) need |= L.cnt[lane] > kMCap - kMRows;
+            need = __any(need);
+            if (lane == 0) L.need = need ? 1 : 0;
+        }
+        multi_barrier();
+        if (L.need) {
             constexpr int NL = kMQ / kMWaves;                     // lists per wave: wave w owns queries w, w + 4, ...
             uint64_t* lists[NL];
             int n[NL], nmax = 0;
@@ -215,17 +242,20 @@ __global__ __launch_bounds__(kMWaves * 64) void scan_multi_kernel(const float* _
                     L.tau[qi] = n[q] >= k ? lists[q][k - 1] : 0ull;
                 }
             }
-            __syncthreads();
+            multi_barrier();                                      // new counts / thresholds visible before the next appends
         }
     }
-    // this workgroup's best k per query (sorted, 0-padded); a workgroup with no chunk leaves zeros
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the two look-ahead slices past the end
+    __syncthreads();
+    // this workgroup's best k per query (sorted, 0-padded); a workgroup with no tile leaves zeros
     for (int i = tid; i < n_q * k; i += kMWaves * 64) {
         const int qi = i / k, t = i - qi * k;
         out[((size_t)qi * gridDim.x + blockIdx.x) * k + t] = t < L.cnt[qi] ? L.keys[qi][t] : 0ull;
     }
 }
 
-// One workgroup per query: see topk_final_kernel.  Row r was scanned by workgroup (r / kMRows) % n_blocks.
+// One workgroup per query: see topk_final_kernel.  Row r lies in tile r / 16, which wave (tile % (4 n_blocks)) of the
+// grid scanned, i.e. workgroup (tile % (4 n_blocks)) / 4.
 __global__ __launch_bounds__(1024) void topk_final_multi_kernel(const uint64_t* __restrict__ cand, int n_blocks, int k,
                                                                 int k_eff, int64_t* __restrict__ idx_out,
                                                                 float* __restrict__ sim_out, int32_t* __restrict__ n_out,
@@ -257,7 +287,7 @@ __global__ __launch_bounds__(1024) void topk_final_multi_kernel(const uint64_t* 
             const uint64_t top = mx[t / k];
             if (top != 0ull) {
                 const int64_t row = (int64_t)(top & 0xFFFFFFFFull);
-                const int blk = (int)((row / kMRows) % n_blocks);
+                const int blk = (int)(((row / kMTileRows) % ((int64_t)n_blocks * kMWaves)) / kMWaves);
                 key = c[(size_t)blk * k + (t % k)];
             }
         }
@@ -281,9 +311,9 @@ __global__ __launch_bounds__(1024) void topk_final_multi_kernel(const uint64_t* 
     }
 }
 
-static int multi_grid(int64_t n_rows) {
+static int multi_grid(int64_t n_rows) {                        // one workgroup per CU (its LDS fills the CU), 64 rows per round
     const int64_t chunks = (n_rows + kMRows - 1) / kMRows;
-    return (int)(chunks < 2 * kNumCU ? chunks : 2 * kNumCU);
+    return (int)(chunks < kNumCU ? chunks : kNumCU);
 }
 
 }  // namespace hmm
@@ -332,7 +362,7 @@ extern "C" int hmm_cosine_topk_multi(const float* store_dev, int64_t n_rows, int
     for (int q0 = 0; q0 < n_queries; q0 += kMQ) {                  // 16 queries per pass over the store
         const int nq = n_queries - q0 < kMQ ? n_queries - q0 : kMQ;
         scan_multi_kernel<<<grid, kMWaves * 64, sizeof(MultiLds), st>>>(store_dev, n_rows, queries_dev + (size_t)q0 * dim,
-                                                                       nq, k_eff, cand, 1);
+                                                                       nq, k_eff, cand);
         HMM_LAUNCH_CHECK();
         topk_final_multi_kernel<<<nq, 1024, 0, st>>>(cand, grid, k_eff, k_eff, idx_out_dev + (size_t)q0 * k,
                                                      sim_out_dev + (size_t)q0 * k, n_out_dev ? n_out_dev + q0 : nullptr, k);

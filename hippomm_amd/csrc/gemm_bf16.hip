@@ -41,8 +41,8 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 // Shared epilogue.  A lane holds C[m][n..n+3] for m = m_lane + 16*mi, n = n_lane + 16*ni.  The bias
-// vectors are loaded once per lane (not per store).  For EPI_BIAS_RESID_F32 the residual is already in the
-// accumulators (they were initialised from C), so this only adds the bias and stores.
+// vectors are loaded once per lane (not per store), and the fp32 residual read-modify-write is
+// software-pipelined one row-block ahead so that its load latency is not paid per element.
 template <int EPI, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float* __restrict__ bias,
                                               void* __restrict__ Cout, int M, int N, int m_lane, int n_lane) {
@@ -51,7 +51,33 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float*
     for (int ni = 0; ni < NI; ++ni)
         bv[ni] = bias ? *reinterpret_cast<const float4*>(bias + n_lane + ni * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    {
+    if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
+        float* C = static_cast<float*>(Cout);
+        float4 xin[2][NI];
+        auto load_row = [&](int mi, float4 (&dst)[NI]) {
+            const int m = m_lane + mi * 16;
+            if (m < M) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    dst[ni] = *reinterpret_cast<const float4*>(C + (size_t)m * N + n_lane + ni * 16);
+            }
+        };
+        load_row(0, xin[0]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if (mi + 1 < MI) load_row(mi + 1, xin[(mi + 1) & 1]);
+            const int m = m_lane + mi * 16;
+            if (m < M) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const float4 x = xin[mi & 1][ni];
+                    const f32x4 v = acc[mi][ni];
+                    *reinterpret_cast<float4*>(C + (size_t)m * N + n_lane + ni * 16) =
+                        make_float4(x.x + v[0] + bv[ni].x, x.y + v[1] + bv[ni].y, x.z + v[2] + bv[ni].z, x.w + v[3] + bv[ni].w);
+                }
+            }
+        }
+    } else {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int m = m_lane + mi * 16;
@@ -61,7 +87,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float*
                 f32x4 v = acc[mi][ni];
                 v[0] += bv[ni].x; v[1] += bv[ni].y; v[2] += bv[ni].z; v[3] += bv[ni].w;
                 const size_t o = (size_t)m * N + n_lane + ni * 16;
-                if constexpr (EPI == HMM_EPI_F32 || EPI == HMM_EPI_BIAS_RESID_F32) {   // residual: already in the accumulator
+                if constexpr (EPI == HMM_EPI_F32) {
                     *reinterpret_cast<float4*>(static_cast<float*>(Cout) + o) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     if constexpr (EPI == HMM_EPI_BIAS_GELU_BF16) {
@@ -135,22 +161,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
     const int c_k0 = ((lane >> 4) ^ fsw) * 16;           // kh = 0
     const int c_k1 = ((4 + (lane >> 4)) ^ fsw) * 16;     // kh = 1
 
-    // EPI_BIAS_RESID_F32: the accumulators START from the fp32 residual tile (C-in of the first MFMA), so the epilogue only
-    // adds the bias and stores -- no read-modify-write burst behind the main loop.  Every geometry does the same, in the
-    // same K order, so results stay bitwise equal across geometries.
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
-                const int m = m0 + wm * TM + mi * 16 + (lane & 15);
-                if (m < M)
-                    acc[mi][ni] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(Cout) + (size_t)m * N + n0 +
-                                                                   wn * TN + ni * 16 + 4 * (lane >> 4));
-            }
-        }
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = K / 64;
     stage(0, 0);
@@ -192,8 +207,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
 // measured store-issue-bound at ~7 B/clk/CU (22 % of the qkv GEMM).  After the main loop the LDS is
 // idle, so each wave parks its 128x64 sub-tile in a private LDS slab (row stride padded against
 // bank conflicts), reads it back row-major and stores 16 B per lane: every wave-instruction then
-// writes 8 whole 128-B lines (bf16) / 4 rows x 256 B (fp32).  fp32 outputs go in two 64-row halves to fit the
-// slab.  (EPI_BIAS_RESID_F32: the residual entered through the accumulators at the start of the tile.)
+// writes 8 whole 128-B lines (bf16) / 4 rows x 256 B (fp32), and the fp32 residual is read with the
+// same shape.  fp32 outputs go in two 64-row halves to fit the slab.
 constexpr int kEpiSlab = 18432;                      // per-wave LDS slab: 128 rows x 144 B (bf16) / 64 x 272 B (fp32)
 
 template <int EPI>
@@ -237,6 +252,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
         const int rsub = lane >> 4, chunk = lane & 15;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+            float4 xin[16];
+            if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {       // residual reads issued first: they fly during the transpose
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int m = m_wave + half * 64 + it * 4 + rsub;
+                    xin[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m < M) xin[it] = *reinterpret_cast<const float4*>(C + (size_t)m * N + n_wave + chunk * 4);
+                }
+            }
             if (half == 1) {                                      // slab is re-used: previous reads must be done
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
@@ -256,6 +280,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
                 const int row = it * 4 + rsub;
                 float4 v = *reinterpret_cast<const float4*>(slab + row * RS + chunk * 16);
                 const int m = m_wave + half * 64 + row;
+                if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
+                    v.x += xin[it].x; v.y += xin[it].y; v.z += xin[it].z; v.w += xin[it].w;
+                }
                 if (m < M) *reinterpret_cast<float4*>(C + (size_t)m * N + n_wave + chunk * 4) = v;
             }
         }
@@ -362,30 +389,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const char* a_rd = smem + (wm * 64 + (lane & 15)) * 128;
     const char* b_rd = smem + (wn * 32 + (lane & 15)) * 128;
 
-    // Accumulators.  EPI_BIAS_RESID_F32: they start from the fp32 residual tile (the in-place C), fetched FIRST so that
-    // the 256 KiB per tile fly under the LDS-DMA fill of the first K-tiles instead of stalling the epilogue with a
-    // read-modify-write burst (measured: 16 us of a 48-us out-proj tile).  The loads are inline asm on purpose: beside
-    // LDS-DMA in flight hipcc would drain everything (vmcnt(0)) at the first MFMA that reads an ordinary load's result;
-    // hidden from it, they are covered by the prologue's counted vmcnt(8) (VMEM operations retire in issue order) and
-    // the sched_barrier that follows it.  Rows past M are clamped: their accumulators are never stored.
     f32x4 acc[8][4];
-    if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
-        const float* cin = static_cast<const float*>(Cout) + n0 + wn * 64 + 4 * (lane >> 4);
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            int m = m0 + wm * 128 + mi * 16 + (lane & 15);
-            m = m < M ? m : M - 1;
-            const float* row = cin + (size_t)m * N;
+    for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(acc[mi][ni]) : "v"(row + ni * 16) : "memory");
-        }
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[4][2], blo[2][2], bhi[2][2];
 
 #define HMM_READ_A(buf, half)                                                                         \

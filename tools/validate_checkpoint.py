@@ -90,7 +90,7 @@ def main():
     inputs = {"vision": torch.randn(args.batch, 3, 224, 224, generator=g),
               "audio": torch.randn(args.batch, 3, 1, 128, 204, generator=g),
               "text": torch.tensor([[49406, 320, 1125, 49407] + [0] * 73] * args.batch)}
-    towers = [t for t in args.towers if report[t]["missing_count"] == 0]
+    towers = [t for t in args.towers if report[t]["missing_count"] == 0 and not report[t]["unused"]]   # loadable towers
     if towers:
         depth = {t: args.depth for t in towers} if args.depth > 0 else None
         model = ImageBind(args.checkpoint, towers=tuple(towers), depth=depth)   # the reference's constructor argument
