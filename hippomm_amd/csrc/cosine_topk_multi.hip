@@ -12,8 +12,8 @@
 // Data movement (round 2; round 1 read 16 rows x 64 B per load instruction straight into registers and stopped at
 // 5.0 TB/s of loads):
 //   * the store is streamed by LDS-DMA in 512-B row pieces: one global_load_lds_dwordx4 fetches 2 rows x 512 B
-//     (whole 128-B lines, two contiguous runs), a wave keeps a private ring of 3 slices (16 rows x 128 floats, 8 KiB)
-//     with two slices always in flight behind a counted vmcnt -- no registers are spent on loads;
+//     (whole 128-B lines, two contiguous runs), a wave keeps a private ring of 4 slices (16 rows x 128 floats, 8 KiB)
+//     with three slices always in flight behind a counted vmcnt -- no registers are spent on loads;
 //   * the 16 queries live in REGISTERS: the B operand of lane (q, g) is q[.][16 j + 4 g + s], 256 values per lane for
 //     the whole kernel (one wave per SIMD, 512 registers), so the main loop reads nothing but the A fragments from
 //     LDS: one ds_read_b128 per four MFMAs;
@@ -22,7 +22,9 @@
 //     then touches 16 different 16-B bank slots: conflict-free.
 // Selection is fused: every query has a candidate list of order keys in LDS and a threshold = its current k-th best;
 // only keys above the threshold are appended (LDS atomic), lists are sorted down to k when they could overflow and at
-// the end, and each workgroup leaves its best k keys per query.  A second kernel (one workgroup per query) finishes
+// the end, and each workgroup leaves its best k keys per query.  (Sharing the thresholds chip-wide through one monotone
+// word per query in global memory was built and measured: 0.75 -> 0.83 ms per pass -- the contended line and the atomics
+// sit in the in-order VMEM queue in front of the slice waits.  Not kept.)  A second kernel (one workgroup per query) finishes
 // exactly as topk_final_kernel does: the global top-k lies in the lists of the k workgroups with the largest maxima.
 // Keys, total order (NaN first, higher row first on ties) and outputs are those of hmm_cosine_topk.
 #include "hmm_common.h"
@@ -36,14 +38,14 @@ constexpr int kMRows = kMWaves * kMTileRows;      // rows per workgroup per roun
 constexpr int kMSlices = 8;             // K slices per tile: 128 floats each
 constexpr int kMPiece = 1056;           // LDS bytes per DMA piece: 2 rows x 512 B + 32 B (bank rotation between pieces)
 constexpr int kMSliceBytes = 8 * kMPiece;
-constexpr int kMRing = 3;               // slices per wave: one being read, two in flight
-constexpr int kMCap = 256;              // candidate keys per query and workgroup (>= k + kMRows, power of two)
+constexpr int kMRing = 4;               // slices per wave: one being read, three in flight (96 KiB per CU)
+constexpr int kMCap = 128;              // candidate keys per query and workgroup (>= k + kMRows, power of two)
 constexpr int kMMaxK = 64;              // k*k <= 4096 for the one-kernel finish
 constexpr int kMMaxBlocks = 2048;
 
 struct MultiLds {
-    char ring[kMWaves][kMRing][kMSliceBytes];     // 101376 B
-    uint64_t keys[kMQ][kMCap];                     //  32768 B
+    char ring[kMWaves][kMRing][kMSliceBytes];     // 135168 B
+    uint64_t keys[kMQ][kMCap];                     //  16384 B
     uint64_t tau[kMQ];
     int cnt[kMQ];
     int need;                                      // workgroup-uniform "sort now" flag (written by wave 0 between barriers)
@@ -134,8 +136,7 @@ __global__ __launch_bounds__(kMWaves * 64) void scan_multi_kernel(const float* _
     const int64_t wave_gid = (int64_t)blockIdx.x * kMWaves + wave;
     const int64_t n_rounds = (n_tiles + n_waves - 1) / n_waves;   // same for every wave of the grid
 
-    // DMA source of lane l for piece i of (tile, slice): row 16 tile + 2 i + (l & 1), 16-B chunk 32 slice + (l >> 1)
-    const int src_lane = (lane & 1) * 1024 + (lane >> 1) * 4;     // floats
+    // DMA source of lane l for piece i of (tile, slice): row 16 tile + 2 i + (l & 1), floats 128 slice + 4 (l >> 1) .. + 3
     char* my_ring = L.ring[wave][0];
     auto issue_slice = [&](int64_t tile, int sl, int slot) {
         int64_t row0 = tile * kMTileRows;
@@ -143,19 +144,19 @@ __global__ __launch_bounds__(kMWaves * 64) void scan_multi_kernel(const float* _
         for (int i = 0; i < 8; ++i) {
             int64_t row = row0 + 2 * i + (lane & 1);
             row = row < n_rows ? row : n_rows - 1;                // clamp: rows past the end are masked at selection
-            const float* src = store + row * 1024 + 32 * sl + (lane >> 1) * 4;
+            const float* src = store + row * 1024 + 128 * sl + (lane >> 1) * 4;
             __builtin_amdgcn_global_load_lds(HMM_GLB_PTR(src), HMM_LDS_PTR(my_ring + slot * kMSliceBytes + i * kMPiece),
                                              16, 0, 0);
         }
     };
-    (void)src_lane;
     // A fragment of lane (r16, g), step j: chunk c = 4 j + g of row r16 -> unit 2 c + (r16 & 1) of piece r16 >> 1
     const int a_lane = (r16 >> 1) * kMPiece + (r16 & 1) * 16 + g * 32;
 
-    // flattened (round, slice) sequence n = 8 round + slice; slot n % 3; slices n + 1, n + 2 are in flight while n is read
+    // flattened (round, slice) sequence n = 8 round + slice; slot n % kMRing; slices n + 1 .. n + LA are in flight while n is read
+    constexpr int LA = kMRing - 1;
     auto tile_of = [&](int64_t round) { return wave_gid + round * n_waves; };
-    issue_slice(tile_of(0), 0, 0);
-    issue_slice(tile_of(0), 1, 1);
+#pragma unroll
+    for (int p = 0; p < LA; ++p) issue_slice(tile_of(0), p, p);
     int slot = 0;                                                 // slot of the slice being read
     for (int64_t round = 0; round < n_rounds; ++round) {
         const int64_t tile = tile_of(round);
@@ -164,10 +165,10 @@ __global__ __launch_bounds__(kMWaves * 64) void scan_multi_kernel(const float* _
 #pragma unroll
         for (int sl = 0; sl < kMSlices; ++sl) {
             // refill the slot read in the previous step (its ds_reads were waited for before that step's MFMAs)
-            const int nslot = slot == 0 ? 2 : slot - 1;           // (slot + 2) % 3
-            if (sl + 2 < kMSlices) issue_slice(tile, sl + 2, nslot);
-            else                   issue_slice(tile_of(round + 1), sl + 2 - kMSlices, nslot);   // next round (clamped past the end)
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // slice n has landed; n + 1, n + 2 stay in flight
+            const int nslot = slot == 0 ? kMRing - 1 : slot - 1;  // (slot + LA) % kMRing
+            if (sl + LA < kMSlices) issue_slice(tile, sl + LA, nslot);
+            else                    issue_slice(tile_of(round + 1), sl + LA - kMSlices, nslot);   // next round (clamped past the end)
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LA * 8) : "memory");     // slice n has landed; n + 1 .. n + LA stay in flight
             __builtin_amdgcn_sched_barrier(0);
             const char* ap = my_ring + slot * kMSliceBytes + a_lane;
             f32x4 x[8];
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(kMWaves * 64) void scan_multi_kernel(const float* _
                 ss = fmaf(x[j][0], x[j][0], ss); ss = fmaf(x[j][1], x[j][1], ss);
                 ss = fmaf(x[j][2], x[j][2], ss); ss = fmaf(x[j][3], x[j][3], ss);
             }
-            slot = slot == 2 ? 0 : slot + 1;
+            slot = slot == kMRing - 1 ? 0 : slot + 1;
         }
         // row norms: the four lanes (r16, g = 0..3) of a row hold its partial sums
         ss += __shfl_xor(ss, 16, 64);
@@ -211,7 +212,9 @@ __global__ __launch_bounds__(kMWaves * 64) void scan_multi_kernel(const float* _
         multi_barrier();                                          // every append of this round is visible
         if (wave == 0) {
             bool need = round + 1 >= n_rounds || round == 0;
-            if (lane < kMQ) need |= L.cnt[lane] > kMCap - kMRows;
+            if (lane < kMQ) {
+                need |= L.cnt[lane] > kMCap - kMRows;
+            }
             need = __any(need);
             if (lane == 0) L.need = need ? 1 : 0;
         }
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(kMWaves * 64) void scan_multi_kernel(const float* _
             multi_barrier();                                      // new counts / thresholds visible before the next appends
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the two look-ahead slices past the end
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the look-ahead slices past the end
     __syncthreads();
     // this workgroup's best k per query (sorted, 0-padded); a workgroup with no tile leaves zeros
     for (int i = tid; i < n_q * k; i += kMWaves * 64) {

@@ -1,6 +1,6 @@
 """Time the scan at BASELINE cfg 4 (1M x 1024 fp32, k=32) on one GPU."""
-import sys, time
-sys.path.insert(0, ".")
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from hippomm_amd.vector_ops import FeatureStore
 
