@@ -48,6 +48,7 @@ struct hmm_encoder {
     bool ready = false;
     int device = 0;                         // the device the handle was created on (weights, side stream, events)
     int streams = 2;                        // 2: half-batches on two streams (default), 1: one chain (hmm_encoder_set_streams)
+    bool fused_attention = true;            // vision tower: in_proj + attention as one kernel (hmm_encoder_set_fused_attention)
     hipStream_t side_stream = nullptr;      // second half-batch runs here (see hmm_encoder_forward)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     char* arena = nullptr;
@@ -294,7 +295,9 @@ extern "C" double hmm_encoder_flops_executed(const hmm_encoder* e, int batch) {
     const double D = e->D, T = e->T, H = e->mlp, Lk = e->T + (e->bias_kv ? 1 : 0);
     const bool text = e->tower == HMM_TOWER_TEXT;
     double macs = text ? 0.0 : (double)e->n_patches * e->patch_k_pad * D;          // folded, K-padded patch projection
-    const double full = T * D * (3 * D + D + 2 * H) + 2 * T * Lk * D;               // one whole block
+    double full = T * D * (3 * D + D + 2 * H) + 2 * T * Lk * D;                     // one whole block
+    if (e->fused_attention && e->tower == HMM_TOWER_VISION)                         // fused in_proj: 256-column tile per head (240 used)
+        full += (T - 1) * D * (e->heads * 256.0 - 3 * D);
     // last block of the vision / audio towers: K|V projection of every token, everything else for token 0 only
     const double last = T * D * 2 * D + D * (D + D + 2 * H) + 2 * Lk * D;
     macs += text ? e->depth * full : (e->depth - 1) * full + last;
@@ -344,7 +347,19 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
     const BlockW& w = e->blocks[i];
     HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
     const bool text = e->tower == HMM_TOWER_TEXT;     // the selected (EOS) row differs per sample: no cls-only shortcut
-    if (i + 1 < e->depth || text) {
+    const bool fused = e->fused_attention && e->tower == HMM_TOWER_VISION && D == 1280 && e->heads == 16 && T == 257;
+    if (i + 1 < e->depth && fused) {
+        // in_proj + attention in one kernel per (image, head): the packed qkv matrix never exists in HBM.  The cls rows
+        // (one per image: they do not fit the kernel's 256-row tile) are projected by a small GEMM first; the attention
+        // output lands in `big` because every head of an image still reads all of `a`.  Bitwise equal to the branch below.
+        HMM_TRY(launch_gather_rows(a, (size_t)T * D * 2, ac, n_img, D * 2, st));
+        HMM_TRY(gemm_bf16(ac, w.qkv_w, w.qkv_b, hc, n_img, 3 * D, D, HMM_EPI_BIAS_BF16, -1, st));
+        HMM_TRY(qkv_attention_bf16(a, w.qkv_w, w.qkv_b, hc, big, n_img, st));
+        HMM_TRY(gemm_bf16(big, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, -1, st));
+        HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
+        HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, -1, st));
+        HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, -1, st));
+    } else if (i + 1 < e->depth || text) {
         HMM_TRY(gemm_bf16(a, w.qkv_w, w.qkv_b, big, R, 3 * D, D, HMM_EPI_BIAS_BF16, -1, st));
         HMM_TRY(attention_bf16(big, a, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st, text));
         HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, -1, st));
@@ -441,6 +456,12 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
         }
     }
     return rc;
+}
+
+extern "C" int hmm_encoder_set_fused_attention(hmm_encoder* e, int on) {
+    HMM_REQUIRE(e, HMM_E_INVALID, "encoder_set_fused_attention: null handle");
+    e->fused_attention = on != 0;
+    return HMM_OK;
 }
 
 extern "C" int hmm_encoder_set_streams(hmm_encoder* e, int n_streams) {

@@ -29,6 +29,11 @@ int launch_fold_conv3d(const float* w, bf16_t* dst, int D, hipStream_t st);
 int attention_bf16(const bf16_t* qkv, bf16_t* out, int batch, int tokens, int heads, int head_dim,
                    const float* bias_k, const float* bias_v, hipStream_t st, bool causal = false);
 
+// vision tower only (D 1280, 16 heads, 257 tokens): in_proj + attention in one kernel (qkv_attention.hip); qkv_cls is the
+// [n_img][3D] projection of the cls rows, out is [n_img*257][D]
+int qkv_attention_bf16(const bf16_t* a, const bf16_t* w, const float* bias, const bf16_t* qkv_cls, bf16_t* out,
+                       int n_img, hipStream_t st);
+
 // last block: one query (the cls token) per (image, head); kv is [rows][2D] = [k | v]
 int attention_cls_bf16(const bf16_t* q_cls, const bf16_t* kv, bf16_t* out, int batch, int tokens, int heads,
                        int head_dim, const float* bias_k, const float* bias_v, hipStream_t st);

@@ -15,11 +15,9 @@
 //   - tile order is remapped so that the blocks that land on one XCD (blockIdx % 8) walk
 //     neighbouring tiles and share A / W panels in that XCD's L2.
 #include "hmm_common.h"
+#include "gemm_pp_mainloop.h"
 
 namespace hmm {
-
-#define HMM_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-#define HMM_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
 // GELU(x) = 0.5 x (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.26:
 //   erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3 + a4 t^4 + a5 t^5) exp(-z^2),  t = 1 / (1 + p z),  z >= 0,
@@ -312,16 +310,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
 // were measured and rejected are recorded in DESIGN.md section 4.3 / 4.5, not kept in the code.
 // ------------------------------------------------------------------------------------------------
 #ifdef HMM_PROBE
-// probe build: first-round workgroups of slot group ((blockIdx/8) % groups) start `units` x ~1 us x group late, so that
-// the CUs of one XCD do not run their epilogue store bursts at the same instant
-HMM_TUNABLE(int, g_gemm_dephase_units, 0)
-HMM_TUNABLE(int, g_gemm_dephase_groups, 4)
-// in-kernel stamps (s_memrealtime, 100 MHz): per workgroup {start, first K-tile landed, main loop done, stores retired,
-// XCC id, HW id}; written to a buffer of their own that nothing else reads
+// in-kernel stamps (s_memrealtime, 100 MHz): per workgroup {start, -, main loop done, stores retired, XCC id, HW id};
+// written to a buffer of their own that nothing else reads
 unsigned long long* g_gemm_stamps = nullptr;
 extern "C" void hmm_probe_set_gemm_stamps(unsigned long long* p) { g_gemm_stamps = p; }
-#define HMM_PROBE_ARG , int dephase, unsigned long long* stamps
-#define HMM_PROBE_VAL , (g_gemm_dephase_groups << 16) | g_gemm_dephase_units, g_gemm_stamps
+#define HMM_PROBE_ARG , unsigned long long* stamps
+#define HMM_PROBE_VAL , g_gemm_stamps
 #define HMM_STAMP(slot)                                                                              \
     if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();
 #else
@@ -334,8 +328,6 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     void* __restrict__ Cout, int M, int N, int K, int tiles_n HMM_PROBE_ARG) {
-    constexpr int HALF = 16384, TILE = 4 * HALF;
-    constexpr int H_ALO = 0, H_AHI = HALF, H_BLO = 2 * HALF, H_BHI = 3 * HALF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -352,15 +344,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
         stamps[(size_t)bid * 8 + 4] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
         stamps[(size_t)bid * 8 + 5] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
     }
-    if ((dephase & 0xFFFF) && bid < kNumCU) {
-        const int grp = (bid >> 3) % (dephase >> 16);
-        for (int i = 0; i < grp * (dephase & 0xFFFF); ++i) __builtin_amdgcn_s_sleep(32);
-    }
 #endif
 
     // staging sources as 32-bit element offsets from A / W (launcher guarantees M*K, N*K < 2^31):
     // half-tile local row lr = (wave + 8j)*8 + (lane>>3), 16-B chunk (lane&7) un-swizzled
-    int src_alo[2], src_ahi[2], src_blo[2], src_bhi[2];
+    PPSources src;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int lr = (wave + 8 * j) * 8 + (lane >> 3);
@@ -369,100 +357,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
         int g0 = m0 + arow, g1 = m0 + arow + 64;
         g0 = g0 < M ? g0 : M - 1;
         g1 = g1 < M ? g1 : M - 1;
-        src_alo[j] = g0 * K + c * 8;
-        src_ahi[j] = g1 * K + c * 8;
+        src.alo[j] = g0 * K + c * 8;
+        src.ahi[j] = g1 * K + c * 8;
         const int bcol = (lr >> 5) * 64 + (lr & 31);             // cols 0..31 of each wave-column
-        src_blo[j] = (n0 + bcol) * K + c * 8;
-        src_bhi[j] = (n0 + bcol + 32) * K + c * 8;
+        src.blo[j] = (n0 + bcol) * K + c * 8;
+        src.bhi[j] = (n0 + bcol + 32) * K + c * 8;
     }
-#define HMM_STAGE(base, src, kt, buf, half)                                                                 \
-    do {                                                                                                    \
-        __builtin_amdgcn_global_load_lds(HMM_GLB_PTR((base) + (ptrdiff_t)(src[0] + (kt) * 64)),             \
-                                         HMM_LDS_PTR(smem + (buf) * TILE + (half) + wave * 1024), 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds(HMM_GLB_PTR((base) + (ptrdiff_t)(src[1] + (kt) * 64)),             \
-                                         HMM_LDS_PTR(smem + (buf) * TILE + (half) + (wave + 8) * 1024), 16, 0, 0); \
-    } while (0)
-
-    // fragment read bases (bytes inside a half-tile)
-    const int fsw = (lane & 15) >> 1;
-    const int ck0 = ((lane >> 4) ^ fsw) * 16, ck1 = ((4 + (lane >> 4)) ^ fsw) * 16;
-    const char* a_rd = smem + (wm * 64 + (lane & 15)) * 128;
-    const char* b_rd = smem + (wn * 32 + (lane & 15)) * 128;
 
     f32x4 acc[8][4];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[4][2], blo[2][2], bhi[2][2];
 
-#define HMM_READ_A(buf, half)                                                                         \
-    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                  \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
-        af[mi][kh] = *reinterpret_cast<const bf16x8*>(a_rd + (buf) * TILE + (half) + mi * 2048 + (kh ? ck1 : ck0));
-#define HMM_READ_B(dst, buf, half)                                                                    \
-    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                  \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
-        dst[ni][kh] = *reinterpret_cast<const bf16x8*>(b_rd + (buf) * TILE + (half) + ni * 2048 + (kh ? ck1 : ck0));
-#define HMM_MFMA_QUAD(mo, no, bsrc)                                                                   \
-    __builtin_amdgcn_s_setprio(1);                                                                    \
-    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                  \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
-        acc[(mo) + mi][(no) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[ni][kh], af[mi][kh], \
-                                                                            acc[(mo) + mi][(no) + ni], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);
-#define HMM_BAR()                              \
-    __builtin_amdgcn_sched_barrier(0);         \
-    __builtin_amdgcn_s_barrier();              \
-    __builtin_amdgcn_sched_barrier(0);
-#define HMM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-    const int KT = K >> 6;                                    // even, >= 2 (checked by the launcher)
-    // prologue: K-tiles 0 and 1 complete; wait for tile 0 only
-    HMM_STAGE(A, src_alo, 0, 0, H_ALO); HMM_STAGE(W, src_blo, 0, 0, H_BLO);
-    HMM_STAGE(W, src_bhi, 0, 0, H_BHI); HMM_STAGE(A, src_ahi, 0, 0, H_AHI);
-    HMM_STAGE(A, src_alo, 1, 1, H_ALO); HMM_STAGE(W, src_blo, 1, 1, H_BLO);
-    HMM_STAGE(W, src_bhi, 1, 1, H_BHI); HMM_STAGE(A, src_ahi, 1, 1, H_AHI);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    HMM_BAR();
-    HMM_STAMP(1)
-    if (wm == 1) { HMM_BAR(); }                               // waves 4-7 run one barrier behind
-
-#define HMM_KTILE(t, buf)                                                                 \
-    {                                                                                     \
-        /* P1: quadrant (lo,lo) */                                                        \
-        HMM_READ_A(buf, H_ALO) HMM_READ_B(blo, buf, H_BLO)                                \
-        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(0, 0, blo) HMM_BAR()                         \
-        /* P2: (lo,hi) */                                                                 \
-        HMM_READ_B(bhi, buf, H_BHI)                                                       \
-        if ((t) + 2 < KT) HMM_STAGE(A, src_alo, (t) + 2, buf, H_ALO);                     \
-        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(0, 2, bhi) HMM_BAR()                         \
-        /* P3: (hi,hi) */                                                                 \
-        HMM_READ_A(buf, H_AHI)                                                            \
-        if ((t) + 2 < KT) HMM_STAGE(W, src_blo, (t) + 2, buf, H_BLO);                     \
-        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(4, 2, bhi) HMM_BAR()                         \
-        /* P4: (hi,lo); retire K-tile t+1, leave the four half-tiles of t+2 in flight */  \
-        if ((t) + 2 < KT) {                                                               \
-            HMM_STAGE(W, src_bhi, (t) + 2, buf, H_BHI);                                   \
-            HMM_STAGE(A, src_ahi, (t) + 2, buf, H_AHI);                                   \
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                              \
-        } else {                                                                          \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              \
-        }                                                                                 \
-        HMM_BAR() HMM_MFMA_QUAD(4, 0, blo) HMM_BAR()                                      \
-    }
-
-    for (int t = 0; t < KT; t += 2) {
-        HMM_KTILE(t, 0)
-        HMM_KTILE(t + 1, 1)
-    }
-    if (wm == 0) { HMM_BAR(); }                               // re-align the two wave groups
-#undef HMM_KTILE
-#undef HMM_STAGE
-#undef HMM_READ_A
-#undef HMM_READ_B
-#undef HMM_MFMA_QUAD
+    pp_mainloop(A, W, src, K >> 6, smem, lane, wave, acc);   // K/64 even, >= 2 (checked by the launcher)
 
     // every wave is past its last LDS read and every DMA has landed: the LDS is free
     HMM_STAMP(2)

@@ -109,6 +109,10 @@ class HipTower:
         """FLOPs this build executes for the same forward (folded patch conv, cls-only last block)."""
         return float(self._lib.hmm_encoder_flops_executed(self._h, batch))
 
+    def set_fused_attention(self, on: bool):
+        """Vision tower: in_proj + attention as one kernel (default) or as GEMM + attention kernel; same bits."""
+        _lib.check(self._lib.hmm_encoder_set_fused_attention(self._h, int(bool(on))), "hmm_encoder_set_fused_attention")
+
     def set_streams(self, n: int):
         """2 (default): half-batches on two streams from batch*clips >= 64 on; 1: a single chain."""
         _lib.check(self._lib.hmm_encoder_set_streams(self._h, int(n)), "hmm_encoder_set_streams")

@@ -157,6 +157,10 @@ double hmm_encoder_flops_executed(const hmm_encoder* enc, int batch);
  * by the handle (forked from / joined to the caller's stream with events).  n_streams = 1: one chain on the caller's
  * stream only.  Embeddings are bitwise identical either way (tests/test_gpu_encoder_batch.py). */
 int  hmm_encoder_set_streams(hmm_encoder* enc, int n_streams);
+/* Vision tower: on (default) = in_proj and the attention core of a block run as ONE kernel per (image, head) and the
+ * packed qkv matrix never goes through HBM; off = a QKV GEMM followed by the attention kernel.  Embeddings are bitwise
+ * identical either way.  No effect on the audio / text towers (their head shapes keep the two-kernel path). */
+int  hmm_encoder_set_fused_attention(hmm_encoder* enc, int on);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side vision preprocessing.  Replaces, for already decoded frames, the transform chain of
@@ -227,6 +231,12 @@ int hmm_op_layernorm_bf16(const float* x_dev, const float* gamma_dev, const floa
 int hmm_op_attention_bf16(const uint16_t* qkv_dev, uint16_t* out_dev, int batch, int tokens,
                           int heads, int head_dim, const float* bias_k_dev, const float* bias_v_dev,
                           hmm_stream_t stream);
+/* Fused in_proj + attention of the vision tower (D = 1280, 16 heads of 80, 257 tokens per image): a_dev [n_img*257][1280]
+ * bf16 (LayerNorm output), w_dev [3840][1280] bf16 + bias_dev [3840] (packed in_proj), qkv_cls_dev [n_img][3840] bf16 =
+ * the projection of each image's token 0 (hmm_op_gemm_bf16 on the gathered cls rows), out_dev [n_img*257][1280] bf16.
+ * Bitwise equal to hmm_op_gemm_bf16(HMM_EPI_BIAS_BF16) + hmm_op_attention_bf16. */
+int hmm_op_qkv_attention_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
+                              const uint16_t* qkv_cls_dev, uint16_t* out_dev, int n_img, hmm_stream_t stream);
 /* Causal variant (text tower): key j is visible to query i iff j <= i; no bias_kv. */
 int hmm_op_attention_causal_bf16(const uint16_t* qkv_dev, uint16_t* out_dev, int batch, int tokens,
                                  int heads, int head_dim, hmm_stream_t stream);

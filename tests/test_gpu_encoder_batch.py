@@ -106,6 +106,22 @@ def test_single_stream_option_is_bitwise_neutral():
     assert torch.equal(two, tower(x))
 
 
+@pytest.mark.parametrize("batch", [5, 70])
+def test_fused_attention_option_is_bitwise_neutral(batch):
+    """hmm_encoder_set_fused_attention(0) runs a QKV GEMM + the attention kernel instead of the fused kernel."""
+    from hippomm_amd.encoder import HipTower
+    spec = ib.reduced(ib.VISION_HUGE, 3)
+    st = ib.synthetic_state(spec, seed=21, init="rich")
+    x = _frames(batch, seed=8).cuda()
+    tower = HipTower("vision", st, depth=3)
+    fused = tower(x)
+    tower.set_fused_attention(False)
+    plain = tower(x)
+    tower.set_fused_attention(True)
+    assert torch.equal(fused, plain)
+    _check(fused[:2], ib.vision_forward(x[:2].cpu(), st, spec), what=f"vision depth3 B={batch} fused attention")
+
+
 def test_full_depth_vision_batch256_bitwise_batch_invariance():
     """32 blocks at BASELINE cfg 2: the benchmarked configuration equals the oracle-checked small-batch path bit for bit,
     and its first frames match the fp32 oracle."""

@@ -248,3 +248,38 @@ def test_attention_one_hot_rows_pick_the_right_value():
                                           bv.data_ptr() if bias else None, L.stream_ptr()), "attention")
         want = v[torch.tensor([top[int(a)] for a in axis])].reshape(T, D)
         assert torch.equal(out.float().cpu(), want)
+
+
+@pytest.mark.parametrize("n_img", [1, 3, 9])
+def test_fused_qkv_attention_equals_gemm_plus_attention(n_img):
+    """hmm_op_qkv_attention_bf16 (vision tower: in_proj + attention in one kernel per (image, head)) against the two
+    kernels it replaces on the same operands: BITWISE equal, and both close to the fp32 torch reference."""
+    L, lib = _lib()
+    T, D, H, dh = 257, 1280, 16, 80
+    g = torch.Generator().manual_seed(100 + n_img)
+    a = _bf16(torch.randn(n_img * T, D, generator=g))
+    w = _bf16(torch.randn(3 * D, D, generator=g) * 0.03)
+    bias = torch.randn(3 * D, generator=g) * 0.1
+    ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+    qkv = torch.empty(n_img * T, 3 * D, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_gemm_bf16(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), qkv.data_ptr(), n_img * T, 3 * D, D,
+                                 EPI_BIAS_BF16, L.stream_ptr()), "gemm")
+    two = torch.full((n_img * T, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_attention_bf16(qkv.data_ptr(), two.data_ptr(), n_img, T, H, dh, None, None, L.stream_ptr()), "attention")
+    # fused: the cls rows are projected separately (M = n_img GEMM on the gathered rows)
+    cls_rows = ad.view(n_img, T, D)[:, 0].contiguous()
+    qkv_cls = torch.empty(n_img, 3 * D, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_gemm_bf16(cls_rows.data_ptr(), wd.data_ptr(), bd.data_ptr(), qkv_cls.data_ptr(), n_img, 3 * D, D,
+                                 EPI_BIAS_BF16, L.stream_ptr()), "gemm cls")
+    assert torch.equal(qkv_cls, qkv.view(n_img, T, 3 * D)[:, 0]), "small-M GEMM differs from the large one on the cls rows"
+    one = torch.full((n_img * T, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_qkv_attention_bf16(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), qkv_cls.data_ptr(), one.data_ptr(),
+                                          n_img, L.stream_ptr()), "qkv_attention")
+    assert torch.isfinite(one.float()).all()
+    assert torch.equal(one, two), f"max diff {(one.float() - two.float()).abs().max().item()}"
+    # and against fp32 torch on the bf16-rounded qkv (the attention test's tolerance)
+    q, k, v = qkv.float().cpu().reshape(n_img, T, 3, H, dh).unbind(2)
+    q, k, v = (t.permute(0, 2, 1, 3) for t in (q, k, v))
+    want = (torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1) @ v).permute(0, 2, 1, 3).reshape(n_img * T, D)
+    tol = 2.0 ** -8 * want.abs() + 2.0 ** -8 * v.abs().max() + 1e-4
+    assert not ((one.float().cpu() - want).abs() > tol).any()

@@ -12,6 +12,7 @@ from probe_common import load_probe, setter, event_ms
 import torch
 
 L, lib = load_probe()
+tower = None
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 no_tower = "--no-tower" in sys.argv
 json_out = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
@@ -31,7 +32,25 @@ wo = (torch.randn(D, D, device=dev) * 0.02).to(torch.bfloat16); bo = torch.zeros
 w1 = (torch.randn(MLP, D, device=dev) * 0.02).to(torch.bfloat16); bb1 = torch.zeros(MLP, device=dev)
 w2 = (torch.randn(D, MLP, device=dev) * 0.02).to(torch.bfloat16); bb2 = torch.zeros(D, device=dev)
 S = L.stream_ptr
-steps = [
+cls_rows = torch.empty(B, D, dtype=torch.bfloat16, device=dev)
+qkv_cls = torch.empty(B, 3 * D, dtype=torch.bfloat16, device=dev)
+
+
+def cls_proj():
+    cls_rows.copy_(a.view(B, T, D)[:, 0])
+    return lib.hmm_op_gemm_bf16(cls_rows.data_ptr(), wq.data_ptr(), bq.data_ptr(), qkv_cls.data_ptr(), B, 3 * D, D, 0, S())
+
+
+steps_fused = [
+    ("ln1", lambda: lib.hmm_op_layernorm_bf16(x.data_ptr(), g1.data_ptr(), b1.data_ptr(), a.data_ptr(), R, D, 1e-6, S())),
+    ("clsqkv", cls_proj),
+    ("qkvattn", lambda: lib.hmm_op_qkv_attention_bf16(a.data_ptr(), wq.data_ptr(), bq.data_ptr(), qkv_cls.data_ptr(), big.data_ptr(), B, S())),
+    ("out", lambda: lib.hmm_op_gemm_bf16(big.data_ptr(), wo.data_ptr(), bo.data_ptr(), x.data_ptr(), R, D, D, 2, S())),
+    ("ln2", lambda: lib.hmm_op_layernorm_bf16(x.data_ptr(), g1.data_ptr(), b1.data_ptr(), a.data_ptr(), R, D, 1e-6, S())),
+    ("fc1", lambda: lib.hmm_op_gemm_bf16(a.data_ptr(), w1.data_ptr(), bb1.data_ptr(), big.data_ptr(), R, MLP, D, 1, S())),
+    ("fc2", lambda: lib.hmm_op_gemm_bf16(big.data_ptr(), w2.data_ptr(), bb2.data_ptr(), x.data_ptr(), R, D, MLP, 2, S())),
+]
+steps_plain = [
     ("ln1", lambda: lib.hmm_op_layernorm_bf16(x.data_ptr(), g1.data_ptr(), b1.data_ptr(), a.data_ptr(), R, D, 1e-6, S())),
     ("qkv", lambda: lib.hmm_op_gemm_bf16(a.data_ptr(), wq.data_ptr(), bq.data_ptr(), big.data_ptr(), R, 3 * D, D, 0, S())),
     ("attn", lambda: lib.hmm_op_attention_bf16(big.data_ptr(), a.data_ptr(), B, T, H, D // H, None, None, S())),
@@ -42,9 +61,18 @@ steps = [
 ]
 
 
+steps = steps_plain
+
+
 def apply(cfg):
+    global steps
     for k, v in cfg.items():
-        setter(lib, k)(v)
+        if k == "fused":                     # pseudo-knob: fused in_proj + attention kernel vs GEMM + attention
+            steps = steps_fused if v else steps_plain
+            if tower is not None:
+                tower.set_fused_attention(bool(v))
+        else:
+            setter(lib, k)(v)
 
 
 def run_layers(n_layers):
@@ -61,7 +89,7 @@ def run_layers(n_layers):
     return {k: sorted(v)[len(v) // 2] for k, v in acc.items()}
 
 
-tower = frames = emb = None
+frames = emb = None
 if not no_tower:
     from hippomm_amd.encoder import HipTower, synthetic_state_dict
     sd = synthetic_state_dict(("vision",), seed=1234)
