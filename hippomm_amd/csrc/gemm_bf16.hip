@@ -288,26 +288,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
 }
 
 // ------------------------------------------------------------------------------------------------
-// Ping-pong variant: 256x256x64 tile, 8 waves as 2 (M) x 4 (N), wave tile 128x64 = 4 quadrants of
-// 64x32; one quadrant (16 MFMAs, full K=64) per phase, 4 phases per K-tile.
-//
-// A K-tile lives in LDS as four 16-KiB half-tiles chosen so that each one dies early:
-//   A_lo = the first 64 rows of every wave-row, A_hi = the second 64; B_lo / B_hi likewise in N.
-//   phase 1 (quadrant lo,lo) reads A_lo + B_lo into registers     -> A_lo, B_lo are dead after P1
-//   phase 2 (lo,hi)          reads B_hi, reuses the A_lo registers -> B_hi dead after P2
-//   phase 3 (hi,hi)          reads A_hi, reuses the B_hi registers -> A_hi dead after P3
-//   phase 4 (hi,lo)          reads nothing (B_lo registers kept)
-// so every phase can re-stage exactly one dead half-tile (2 x global_load_lds_dwordx4 per wave):
-//   P2: (t+2).A_lo   P3: (t+2).B_lo   P4: (t+2).B_hi + (t+2).A_hi      (P1, the read-heavy phase, stages nothing)
-// i.e. the LDS-DMA stream runs 1-2 K-tiles ahead of the MFMAs and is never drained in the loop: the only
-// wait is a counted vmcnt(8) in P4, which retires K-tile t+1 (staged >= 4 phases earlier) while the four
-// youngest half-tiles (of t+2) stay in flight.  Waves 4-7 run one barrier behind waves 0-3, so on every
-// SIMD one wave issues its 16-MFMA burst while its partner does its LDS reads and DMA issue.
-// Hazards: a half-tile is re-staged only in a phase after the one whose reads were retired by
-// lgkmcnt(0) *before* that phase's first barrier (WAR); staged data is read only in a phase after
-// the barrier that follows every wave's counted vmcnt (RAW).
-// Tiles are walked in plain strips (whole row tiles, XCD-contiguous); ablations, tile-walk and pipeline variants that
-// were measured and rejected are recorded in DESIGN.md section 4.3 / 4.5, not kept in the code.
+// Ping-pong kernel: 256x256x64 tiles, 8 waves; the K loop lives in gemm_pp_mainloop.h (shared with the fused
+// in_proj + attention kernel).  Tiles are walked in plain strips (whole row tiles, XCD-contiguous); ablations, tile-walk and
+// pipeline variants that were measured and rejected are recorded in DESIGN.md section 4.3 / 4.5, not kept in the code.
 // ------------------------------------------------------------------------------------------------
 #ifdef HMM_PROBE
 // in-kernel stamps (s_memrealtime, 100 MHz): per workgroup {start, -, main loop done, stores retired, XCC id, HW id};
@@ -340,6 +323,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const int m0 = (swz / tiles_n) * 256, n0 = (swz % tiles_n) * 256;
     HMM_STAMP(0)
 #ifdef HMM_PROBE
+    if (stamps && threadIdx.x == 0) stamps[(size_t)bid * 8 + 6] = __builtin_amdgcn_s_memtime();
     if (stamps && threadIdx.x == 0) {
         stamps[(size_t)bid * 8 + 4] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
         stamps[(size_t)bid * 8 + 5] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
@@ -374,6 +358,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 
     // every wave is past its last LDS read and every DMA has landed: the LDS is free
     HMM_STAMP(2)
+#ifdef HMM_PROBE
+    if (stamps && threadIdx.x == 0) stamps[(size_t)bid * 8 + 7] = __builtin_amdgcn_s_memtime();     // shader-clock ticks
+#endif
     gemm_epilogue_lds<EPI>(acc, bias, Cout, M, N, m0 + wm * 128, n0 + wn * 64, smem + wave * kEpiSlab, lane);
 #ifdef HMM_PROBE
     if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -384,9 +371,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 template <int EPI>
 static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, hipStream_t st) {
     constexpr int LDS = 8 * kEpiSlab > 2 * 4 * 16384 ? 8 * kEpiSlab : 2 * 4 * 16384;
+    const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
     auto kern = gemm_bf16_pp_kernel<EPI>;
     HMM_ENSURE_DYN_LDS(kern, LDS);
-    const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
     kern<<<tiles_m * tiles_n, 512, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n HMM_PROBE_VAL);
     HMM_LAUNCH_CHECK();
     return HMM_OK;

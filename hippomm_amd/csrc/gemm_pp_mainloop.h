@@ -2,19 +2,16 @@
 // QKV-projection + attention kernel (qkv_attention.hip) runs exactly the same K loop -- same staging, same MFMA order, same
 // bits -- as the stand-alone GEMM.
 //
-// 8 waves as 2 (M) x 4 (N), wave tile 128x64 = 4 quadrants of 64x32; one quadrant (16 MFMAs, full K=64) per phase,
-// 4 phases per K-tile.  A K-tile lives in LDS as four 16-KiB half-tiles chosen so that each one dies early:
+// 8 waves as 2 (M) x 4 (N), wave tile 128x64 = 4 quadrants of 64x32 (16 MFMAs each for the full K = 64).
+// A K-tile lives in LDS as four 16-KiB half-tiles chosen so that each one dies early:
 //   A_lo = the first 64 rows of every wave-row, A_hi = the second 64; B_lo / B_hi likewise in N.
-//   phase 1 (quadrant lo,lo) reads A_lo + B_lo into registers     -> A_lo, B_lo are dead after P1
-//   phase 2 (lo,hi)          reads B_hi, reuses the A_lo registers -> B_hi dead after P2
-//   phase 3 (hi,hi)          reads A_hi, reuses the B_hi registers -> A_hi dead after P3
-//   phase 4 (hi,lo)          reads nothing (B_lo registers kept)
-// so every phase can re-stage exactly one dead half-tile (2 x global_load_lds_dwordx4 per wave):
-//   P2: (t+2).A_lo   P3: (t+2).B_lo   P4: (t+2).B_hi + (t+2).A_hi      (P1, the read-heavy phase, stages nothing)
-// i.e. the LDS-DMA stream runs 1-2 K-tiles ahead of the MFMAs and is never drained in the loop: the only
-// wait is a counted vmcnt(8) in P4, which retires K-tile t+1 (staged >= 4 phases earlier) while the four
-// youngest half-tiles (of t+2) stay in flight.  Waves 4-7 run one barrier behind waves 0-3, so on every
-// SIMD one wave issues its 16-MFMA burst while its partner does its LDS reads and DMA issue.
+//   phase A (quadrants lo,lo and lo,hi) reads A_lo, B_lo, B_hi into registers -> all three are dead after its reads
+//   phase B (quadrants hi,hi and hi,lo) reads A_hi, reuses the B registers     -> A_hi is dead after its reads
+// so phase B re-stages (t+2).A_lo, B_lo, B_hi and the next phase A re-stages (t+2).A_hi (2 x global_load_lds_dwordx4 per
+// wave and half-tile): the LDS-DMA stream runs 1-2 K-tiles ahead of the MFMAs and is never drained in the loop; the only
+// wait is a counted vmcnt(8) at the end of each read section, which retires the half-tiles the NEXT phase reads (staged two
+// phases earlier) while the 8 youngest pieces stay in flight.  Waves 4-7 run one barrier behind waves 0-3, so on every
+// SIMD one wave issues its 32-MFMA burst while its partner does its LDS reads and DMA issue.
 // Hazards: a half-tile is re-staged only in a phase after the one whose reads were retired by
 // lgkmcnt(0) *before* that phase's first barrier (WAR); staged data is read only in a phase after
 // the barrier that follows every wave's counted vmcnt (RAW).
@@ -41,8 +38,12 @@ constexpr int kPPHalf = 16384, kPPTile = 4 * kPPHalf;     // LDS: 2 K-tiles x 4 
 
 // acc[mi][ni]: rows wm*128 + 16 mi + (lane & 15), columns wn*64 + 16 ni + 4 (lane >> 4) .. + 3 of the tile.
 // KT = K / 64 must be even and >= 2.  On return every wave is past its last LDS read and every DMA has landed.
-__device__ __forceinline__ void pp_mainloop(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const PPSources& src,
-                                            int KT, char* smem, int lane, int wave, f32x4 (&acc)[8][4]) {
+// The quadrants are issued in pairs, 32 MFMAs per burst: a K-tile has 4 barrier intervals, and the partner group's whole
+// read section (16 / 8 fragment reads + its DMA issue) fits under one 512-cycle burst.  (Round 1 ran one quadrant per
+// phase, 8 intervals per K-tile: same bits, 1-3 % slower in the tower.)
+__device__ __forceinline__ void pp_mainloop(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                            const PPSources& src, int KT, char* smem, int lane, int wave,
+                                            f32x4 (&acc)[8][4]) {
     constexpr int HALF = kPPHalf, TILE = kPPTile;
     constexpr int H_ALO = 0, H_AHI = HALF, H_BLO = 2 * HALF, H_BHI = 3 * HALF;
     const int wm = wave >> 2, wn = wave & 3;
@@ -53,14 +54,11 @@ __device__ __forceinline__ void pp_mainloop(const bf16_t* __restrict__ A, const 
         __builtin_amdgcn_global_load_lds(HMM_GLB_PTR((base) + (ptrdiff_t)(s[1] + (kt) * 64)),               \
                                          HMM_LDS_PTR(smem + (buf) * TILE + (half) + (wave + 8) * 1024), 16, 0, 0); \
     } while (0)
-
-    // fragment read bases (bytes inside a half-tile)
     const int fsw = (lane & 15) >> 1;
     const int ck0 = ((lane >> 4) ^ fsw) * 16, ck1 = ((4 + (lane >> 4)) ^ fsw) * 16;
     const char* a_rd = smem + (wm * 64 + (lane & 15)) * 128;
     const char* b_rd = smem + (wn * 32 + (lane & 15)) * 128;
     bf16x8 af[4][2], blo[2][2], bhi[2][2];
-
 #define HMM_READ_A(buf, half)                                                                         \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                  \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
@@ -70,64 +68,67 @@ __device__ __forceinline__ void pp_mainloop(const bf16_t* __restrict__ A, const 
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
         dst[ni][kh] = *reinterpret_cast<const bf16x8*>(b_rd + (buf) * TILE + (half) + ni * 2048 + (kh ? ck1 : ck0));
 #define HMM_MFMA_QUAD(mo, no, bsrc)                                                                   \
-    __builtin_amdgcn_s_setprio(1);                                                                    \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                  \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
         acc[(mo) + mi][(no) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[ni][kh], af[mi][kh], \
-                                                                            acc[(mo) + mi][(no) + ni], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);
+                                                                            acc[(mo) + mi][(no) + ni], 0, 0, 0);
 #define HMM_BAR()                              \
     __builtin_amdgcn_sched_barrier(0);         \
     __builtin_amdgcn_s_barrier();              \
     __builtin_amdgcn_sched_barrier(0);
 #define HMM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define HMM_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 
-    // prologue: K-tiles 0 and 1 complete; wait for tile 0 only
+    // prologue: K-tile 0 complete, K-tile 1 complete; tile 0 must have landed
     HMM_STAGE(A, src.alo, 0, 0, H_ALO); HMM_STAGE(W, src.blo, 0, 0, H_BLO);
     HMM_STAGE(W, src.bhi, 0, 0, H_BHI); HMM_STAGE(A, src.ahi, 0, 0, H_AHI);
     HMM_STAGE(A, src.alo, 1, 1, H_ALO); HMM_STAGE(W, src.blo, 1, 1, H_BLO);
     HMM_STAGE(W, src.bhi, 1, 1, H_BHI); HMM_STAGE(A, src.ahi, 1, 1, H_AHI);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    HMM_VM8();
     HMM_BAR();
     if (wm == 1) { HMM_BAR(); }                               // waves 4-7 run one barrier behind
 
-#define HMM_KTILE(t, buf)                                                                 \
+#define HMM_KTILE2(t, buf)                                                                \
     {                                                                                     \
-        /* P1: quadrant (lo,lo) */                                                        \
-        HMM_READ_A(buf, H_ALO) HMM_READ_B(blo, buf, H_BLO)                                \
-        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(0, 0, blo) HMM_BAR()                         \
-        /* P2: (lo,hi) */                                                                 \
-        HMM_READ_B(bhi, buf, H_BHI)                                                       \
-        if ((t) + 2 < KT) HMM_STAGE(A, src.alo, (t) + 2, buf, H_ALO);                     \
-        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(0, 2, bhi) HMM_BAR()                         \
-        /* P3: (hi,hi) */                                                                 \
+        /* phase A: (lo,lo) + (lo,hi).  (t).A_hi of the OTHER buffer's previous tile died in phase B(t-1): re-stage it */ \
+        HMM_READ_A(buf, H_ALO) HMM_READ_B(blo, buf, H_BLO) HMM_READ_B(bhi, buf, H_BHI)    \
+        if ((t) >= 1 && (t) + 1 < KT) HMM_STAGE(A, src.ahi, (t) + 1, (buf) ^ 1, H_AHI);   \
+        if ((t) + 1 < KT) { HMM_VM8(); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } \
+        HMM_LGKM0(); HMM_BAR()                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                    \
+        HMM_MFMA_QUAD(0, 0, blo) HMM_MFMA_QUAD(0, 2, bhi)                                 \
+        __builtin_amdgcn_s_setprio(0);                                                    \
+        HMM_BAR()                                                                         \
+        /* phase B: (hi,hi) + (hi,lo); A_lo, B_lo, B_hi of this buffer are dead: stage tile t+2 into them */ \
         HMM_READ_A(buf, H_AHI)                                                            \
-        if ((t) + 2 < KT) HMM_STAGE(W, src.blo, (t) + 2, buf, H_BLO);                     \
-        HMM_LGKM0(); HMM_BAR() HMM_MFMA_QUAD(4, 2, bhi) HMM_BAR()                         \
-        /* P4: (hi,lo); retire K-tile t+1, leave the four half-tiles of t+2 in flight */  \
         if ((t) + 2 < KT) {                                                               \
+            HMM_STAGE(A, src.alo, (t) + 2, buf, H_ALO); HMM_STAGE(W, src.blo, (t) + 2, buf, H_BLO); \
             HMM_STAGE(W, src.bhi, (t) + 2, buf, H_BHI);                                   \
-            HMM_STAGE(A, src.ahi, (t) + 2, buf, H_AHI);                                   \
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                              \
+            HMM_VM8();                                                                    \
         } else {                                                                          \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              \
         }                                                                                 \
-        HMM_BAR() HMM_MFMA_QUAD(4, 0, blo) HMM_BAR()                                      \
+        HMM_LGKM0(); HMM_BAR()                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                    \
+        HMM_MFMA_QUAD(4, 2, bhi) HMM_MFMA_QUAD(4, 0, blo)                                 \
+        __builtin_amdgcn_s_setprio(0);                                                    \
+        HMM_BAR()                                                                         \
     }
 
     for (int t = 0; t < KT; t += 2) {
-        HMM_KTILE(t, 0)
-        HMM_KTILE(t + 1, 1)
+        HMM_KTILE2(t, 0)
+        HMM_KTILE2(t + 1, 1)
     }
     if (wm == 0) { HMM_BAR(); }                               // re-align the two wave groups
-#undef HMM_KTILE
+#undef HMM_KTILE2
 #undef HMM_STAGE
 #undef HMM_READ_A
 #undef HMM_READ_B
 #undef HMM_MFMA_QUAD
 #undef HMM_BAR
 #undef HMM_LGKM0
+#undef HMM_VM8
 }
 
 }  // namespace hmm

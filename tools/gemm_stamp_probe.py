@@ -41,14 +41,16 @@ for name, N, K, epi in shapes:
     s = stamps.cpu().numpy().reshape(n_wg, 8)
     t0 = s[:, 0].min()
     start, landed, loop_done, end = [(s[:, i] - t0) / 100.0 for i in range(4)]          # us
+    landed = start                                                                      # slot 1 is no longer stamped: fill + loop together
+    loop_clock_ghz = (s[:, 7] - s[:, 6]) / ((s[:, 2] - s[:, 0]) * 10.0)                 # shader ticks per ns over fill + main loop
     xcc, hw = s[:, 4] & 0xF, s[:, 5]
     cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5)            # cu_id | sh_id | se_id
     rounds = n_wg // 256
     order = np.argsort(start)
     rec = {"M": M, "N": N, "K": K, "workgroups": n_wg, "kernel_ms_plain": round(plain_ms, 4),
            "kernel_ms_stamped": round(stamped_ms, 4),
-           "fill_us": [round(float(np.percentile(landed - start, q)), 2) for q in (10, 50, 90)],
-           "mainloop_us": [round(float(np.percentile(loop_done - landed, q)), 2) for q in (10, 50, 90)],
+           "fill_plus_mainloop_us": [round(float(np.percentile(loop_done - start, q)), 2) for q in (10, 50, 90)],
+           "in_kernel_clock_GHz_fill_plus_mainloop": [round(float(np.percentile(loop_clock_ghz, q)), 3) for q in (10, 50, 90)],
            "epilogue_us": [round(float(np.percentile(end - loop_done, q)), 2) for q in (10, 50, 90)],
            "tile_us": [round(float(np.percentile(end - start, q)), 2) for q in (10, 50, 90)],
            "last_end_us": round(float(end.max()), 2),
