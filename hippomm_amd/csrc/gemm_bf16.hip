@@ -256,7 +256,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
                 for (int it = 0; it < 16; ++it) {
                     const int m = m_wave + half * 64 + it * 4 + rsub;
                     xin[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (m < M) xin[it] = *reinterpret_cast<const float4*>(C + (size_t)m * N + n_wave + chunk * 4);
+                    if (m < M) {                                 // streamed once: non-temporal (out-proj -2 % in the tower, -12 % alone)
+                        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(C + (size_t)m * N + n_wave + chunk * 4));
+                        xin[it] = make_float4(t[0], t[1], t[2], t[3]);
+                    }
                 }
             }
             if (half == 1) {                                      // slab is re-used: previous reads must be done
@@ -281,7 +284,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
                 if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
                     v.x += xin[it].x; v.y += xin[it].y; v.z += xin[it].z; v.w += xin[it].w;
                 }
-                if (m < M) *reinterpret_cast<float4*>(C + (size_t)m * N + n_wave + chunk * 4) = v;
+                if (m < M) {
+                    if constexpr (EPI == HMM_EPI_BIAS_RESID_F32)
+                        __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(C + (size_t)m * N + n_wave + chunk * 4));
+                    else
+                        *reinterpret_cast<float4*>(C + (size_t)m * N + n_wave + chunk * 4) = v;
+                }
             }
         }
     }
