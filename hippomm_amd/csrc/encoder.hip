@@ -295,9 +295,7 @@ extern "C" double hmm_encoder_flops_executed(const hmm_encoder* e, int batch) {
     const double D = e->D, T = e->T, H = e->mlp, Lk = e->T + (e->bias_kv ? 1 : 0);
     const bool text = e->tower == HMM_TOWER_TEXT;
     double macs = text ? 0.0 : (double)e->n_patches * e->patch_k_pad * D;          // folded, K-padded patch projection
-    double full = T * D * (3 * D + D + 2 * H) + 2 * T * Lk * D;                     // one whole block
-    if (e->fused_attention && e->tower == HMM_TOWER_VISION)                         // fused in_proj: 256-column tile per head (240 used)
-        full += (T - 1) * D * (e->heads * 256.0 - 3 * D);
+    const double full = T * D * (3 * D + D + 2 * H) + 2 * T * Lk * D;               // one whole block
     // last block of the vision / audio towers: K|V projection of every token, everything else for token 0 only
     const double last = T * D * 2 * D + D * (D + D + 2 * H) + 2 * Lk * D;
     macs += text ? e->depth * full : (e->depth - 1) * full + last;

@@ -303,10 +303,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
 #ifdef HMM_PROBE
 // in-kernel stamps (s_memrealtime, 100 MHz): per workgroup {start, -, main loop done, stores retired, XCC id, HW id};
 // written to a buffer of their own that nothing else reads
+HMM_TUNABLE(int, g_gemm_walk, 0)   // 0 = strips; (R << 8) | C = blocks of R row tiles x C column tiles inside the XCD-contiguous order
 unsigned long long* g_gemm_stamps = nullptr;
 extern "C" void hmm_probe_set_gemm_stamps(unsigned long long* p) { g_gemm_stamps = p; }
-#define HMM_PROBE_ARG , unsigned long long* stamps
-#define HMM_PROBE_VAL , g_gemm_stamps
+#define HMM_PROBE_ARG , unsigned long long* stamps, int walk
+#define HMM_PROBE_VAL , g_gemm_stamps, g_gemm_walk
 #define HMM_STAMP(slot)                                                                              \
     if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();
 #else
@@ -328,7 +329,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const int nb = gridDim.x, bid = blockIdx.x;
     const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int m0 = (swz / tiles_n) * 256, n0 = (swz % tiles_n) * 256;
+    int m0 = (swz / tiles_n) * 256, n0 = (swz % tiles_n) * 256;
+#ifdef HMM_PROBE
+    if (walk) {
+        const int R = walk >> 8, C = walk & 255, tiles_m = nb / tiles_n;
+        const int rg = swz / (R * tiles_n), rem = swz - rg * R * tiles_n;
+        const int rows_g = tiles_m - R * rg < R ? tiles_m - R * rg : R;
+        const int cg = rem / (rows_g * C), rem2 = rem - cg * rows_g * C;
+        const int wc = tiles_n - C * cg < C ? tiles_n - C * cg : C;
+        m0 = (rg * R + rem2 / wc) * 256;
+        n0 = (cg * C + rem2 % wc) * 256;
+    }
+#endif
     HMM_STAMP(0)
 #ifdef HMM_PROBE
     if (stamps && threadIdx.x == 0) stamps[(size_t)bid * 8 + 6] = __builtin_amdgcn_s_memtime();

@@ -41,12 +41,16 @@ constexpr int kPPHalf = 16384, kPPTile = 4 * kPPHalf;     // LDS: 2 K-tiles x 4 
 // The quadrants are issued in pairs, 32 MFMAs per burst: a K-tile has 4 barrier intervals, and the partner group's whole
 // read section (16 / 8 fragment reads + its DMA issue) fits under one 512-cycle burst.  (Round 1 ran one quadrant per
 // phase, 8 intervals per K-tile: same bits, 1-3 % slower in the tower.)
+// TAIL16 = true (fused in_proj + attention kernel): tile columns 240..255 do not exist -- the waves of the last wave-column
+// (wn == 3) skip the MFMAs of their last 16-column block (acc[..][3] stays zero) instead of multiplying padding.
+template <bool TAIL16 = false>
 __device__ __forceinline__ void pp_mainloop(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                             const PPSources& src, int KT, char* smem, int lane, int wave,
                                             f32x4 (&acc)[8][4]) {
     constexpr int HALF = kPPHalf, TILE = kPPTile;
     constexpr int H_ALO = 0, H_AHI = HALF, H_BLO = 2 * HALF, H_BHI = 3 * HALF;
     const int wm = wave >> 2, wn = wave & 3;
+    const bool skip_tail = TAIL16 && wn == 3;                     // wave-uniform
 #define HMM_STAGE(base, s, kt, buf, half)                                                                   \
     do {                                                                                                    \
         __builtin_amdgcn_global_load_lds(HMM_GLB_PTR((base) + (ptrdiff_t)(s[0] + (kt) * 64)),               \
@@ -71,8 +75,9 @@ __device__ __forceinline__ void pp_mainloop(const bf16_t* __restrict__ A, const 
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                  \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
-        acc[(mo) + mi][(no) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[ni][kh], af[mi][kh], \
-                                                                            acc[(mo) + mi][(no) + ni], 0, 0, 0);
+        if (!(TAIL16 && (no) + ni == 3 && skip_tail))                                                 \
+            acc[(mo) + mi][(no) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[ni][kh], af[mi][kh], \
+                                                                                acc[(mo) + mi][(no) + ni], 0, 0, 0);
 #define HMM_BAR()                              \
     __builtin_amdgcn_sched_barrier(0);         \
     __builtin_amdgcn_s_barrier();              \

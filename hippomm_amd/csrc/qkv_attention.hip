@@ -7,9 +7,9 @@
 // (image, head) pair needs exactly a 257 x 240 slice of it, which fits in LDS.
 //
 // One workgroup (8 waves) per (image, head):
-//   1. the 256 patch rows of the image times the head's 240 rows of in_proj_weight (q | k | v slices, padded to 256 with
-//      16 ignored columns) is ONE 256 x 256 x 1280 tile of the ping-pong GEMM: pp_mainloop() is the stand-alone kernel's
-//      K loop, bit for bit (gemm_pp_mainloop.h); only the staging source addresses differ;
+//   1. the 256 patch rows of the image times the head's 240 rows of in_proj_weight (q | k | v slices; the tile's last 16
+//      columns do not exist and their MFMAs are skipped) is ONE 256 x 256 x 1280 tile of the ping-pong GEMM: pp_mainloop()
+//      is the stand-alone kernel's K loop, bit for bit (gemm_pp_mainloop.h); only the staging source addresses differ;
 //   2. accumulators + in_proj_bias -> bf16 -> the Q / K / V images in LDS (the staging buffers are dead by then), in
 //      the layouts the attention core reads; the cls row (token 0), which does not fit the 256-row tile, comes from a
 //      small GEMM over the cls rows of all images (qkv_cls, computed by the caller with the same weights);
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    pp_mainloop(a, w, src, kFD >> 6, smem, lane, wave, acc);
+    pp_mainloop<true>(a, w, src, kFD >> 6, smem, lane, wave, acc);     // columns 240..255: no MFMAs
 
     // ---- 2. accumulators -> Q / K / V images (the staging buffers are dead: see pp_mainloop) --------------------------
     char* k_lds = smem;
