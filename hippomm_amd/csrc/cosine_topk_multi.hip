@@ -42,6 +42,7 @@ constexpr int kMRing = 4;               // slices per wave: one being read, thre
 constexpr int kMCap = 128;              // candidate keys per query and workgroup (>= k + kMRows, power of two)
 constexpr int kMMaxK = 64;              // k*k <= 4096 for the one-kernel finish
 constexpr int kMMaxBlocks = 2048;
+constexpr int kMDmaAux = 2;             // cache policy of the row stream: 2 = non-temporal (each row is read once)
 
 struct MultiLds {
     char ring[kMWaves][kMRing][kMSliceBytes];     // 135168 B
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(kMWaves * 64) void scan_multi_kernel(const float* _
             row = row < n_rows ? row : n_rows - 1;                // clamp: rows past the end are masked at selection
             const float* src = store + row * 1024 + 128 * sl + (lane >> 1) * 4;
             __builtin_amdgcn_global_load_lds(HMM_GLB_PTR(src), HMM_LDS_PTR(my_ring + slot * kMSliceBytes + i * kMPiece),
-                                             16, 0, 0);
+                                             16, 0, kMDmaAux);
         }
     };
     // A fragment of lane (r16, g), step j: chunk c = 4 j + g of row r16 -> unit 2 c + (r16 & 1) of piece r16 >> 1
