@@ -51,6 +51,8 @@ struct hmm_encoder {
     bool fused_attention = true;            // vision tower: in_proj + attention as one kernel (hmm_encoder_set_fused_attention)
     hipStream_t side_stream = nullptr;      // second half-batch runs here (see hmm_encoder_forward)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t cls_stream[2] = {nullptr, nullptr};   // per chain: the cls-row projection of the fused attention path
+    hipEvent_t ev_x[2] = {nullptr, nullptr}, ev_cls[2] = {nullptr, nullptr};
     char* arena = nullptr;
     size_t arena_bytes = 0;
     std::unordered_map<std::string, ParamSlot> slots;
@@ -208,6 +210,11 @@ extern "C" int hmm_encoder_create(hmm_encoder** out, int tower, int depth) {
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
+    for (int c = 0; c < 2 && err == hipSuccess; ++c) {
+        err = hipStreamCreateWithFlags(&e->cls_stream[c], hipStreamNonBlocking);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_x[c], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_cls[c], hipEventDisableTiming);
+    }
     if (err != hipSuccess) {
         set_error("encoder_create: device allocation (%zu B arena, side stream) failed: %s", e->arena_bytes,
                   hipGetErrorString(err));
@@ -225,6 +232,11 @@ extern "C" void hmm_encoder_destroy(hmm_encoder* e) {
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
+    for (int c = 0; c < 2; ++c) {
+        if (e->ev_x[c]) (void)hipEventDestroy(e->ev_x[c]);
+        if (e->ev_cls[c]) (void)hipEventDestroy(e->ev_cls[c]);
+        if (e->cls_stream[c]) (void)hipStreamDestroy(e->cls_stream[c]);
+    }
     delete e;
 }
 
@@ -304,9 +316,11 @@ extern "C" double hmm_encoder_flops_executed(const hmm_encoder* e, int batch) {
 }
 
 namespace hmm {
+HMM_TUNABLE(int, g_enc_cls_fork, 1)      // probe build: 0 = cls-row projection on the chain's own stream (A/B)
 
 struct Chain {                 // one (half-)batch travelling through the tower on one stream
     const void* input; float* out; char* ws; WsPlan p; hipStream_t st; int batch;
+    hipStream_t cls_st; hipEvent_t ev_x, ev_cls;      // fork for the cls-row projection of the fused attention path
 };
 
 #define HMM_TRY(call) do { int _rc = (call); if (_rc != HMM_OK) return _rc; } while (0)
@@ -343,15 +357,25 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
     bf16_t* hc = reinterpret_cast<bf16_t*>(c.ws + p.off_hc);
     const int D = e->D, T = e->T, R = p.R, n_img = p.n_img;
     const BlockW& w = e->blocks[i];
-    HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
     const bool text = e->tower == HMM_TOWER_TEXT;     // the selected (EOS) row differs per sample: no cls-only shortcut
     const bool fused = e->fused_attention && e->tower == HMM_TOWER_VISION && D == 1280 && e->heads == 16 && T == 257;
+    if (!(i + 1 < e->depth && fused)) HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
     if (i + 1 < e->depth && fused) {
         // in_proj + attention in one kernel per (image, head): the packed qkv matrix never exists in HBM.  The cls rows
-        // (one per image: they do not fit the kernel's 256-row tile) are projected by a small GEMM first; the attention
-        // output lands in `big` because every head of an image still reads all of `a`.  Bitwise equal to the branch below.
-        HMM_TRY(launch_gather_rows(a, (size_t)T * D * 2, ac, n_img, D * 2, st));
-        HMM_TRY(gemm_bf16(ac, w.qkv_w, w.qkv_b, hc, n_img, 3 * D, D, HMM_EPI_BIAS_BF16, -1, st));
+        // (one per image: they do not fit the kernel's 256-row tile) go through LayerNorm + a small GEMM of their own, on a
+        // stream forked from the chain so that these two latency-bound launches run beside the big LayerNorm instead of in
+        // front of the fused kernel (0.9 % of the forward); the attention output lands in `big` because every head of an
+        // image still reads all of `a`.  Bitwise equal to the branch below.
+        hipStream_t cst = g_enc_cls_fork ? c.cls_st : st;
+        if (g_enc_cls_fork) {
+            HMM_HIP_CHECK(hipEventRecord(c.ev_x, st));                       // x of this block is final on `st`
+            HMM_HIP_CHECK(hipStreamWaitEvent(cst, c.ev_x, 0));
+        }
+        HMM_TRY(launch_layernorm_bf16(x, (size_t)T * D, w.ln1_g, w.ln1_b, ac, n_img, D, 1e-6f, cst));     // token 0 of every image
+        HMM_TRY(gemm_bf16(ac, w.qkv_w, w.qkv_b, hc, n_img, 3 * D, D, HMM_EPI_BIAS_BF16, -1, cst));
+        if (g_enc_cls_fork) HMM_HIP_CHECK(hipEventRecord(c.ev_cls, cst));
+        HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
+        if (g_enc_cls_fork) HMM_HIP_CHECK(hipStreamWaitEvent(st, c.ev_cls, 0));
         HMM_TRY(qkv_attention_bf16(a, w.qkv_w, w.qkv_b, hc, big, n_img, st));
         HMM_TRY(gemm_bf16(big, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, -1, st));
         HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
@@ -424,12 +448,13 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
     int n_chains = 1;
     const int b0 = split_point(e, batch);
     if (b0 == 0) {
-        chains[0] = Chain{input_dev, out_dev, ws, ws_plan(e, batch), st, batch};
+        chains[0] = Chain{input_dev, out_dev, ws, ws_plan(e, batch), st, batch, e->cls_stream[0], e->ev_x[0], e->ev_cls[0]};
     } else {
         const WsPlan p0 = ws_plan(e, b0);
-        chains[0] = Chain{input_dev, out_dev, ws, p0, st, b0};
+        chains[0] = Chain{input_dev, out_dev, ws, p0, st, b0, e->cls_stream[0], e->ev_x[0], e->ev_cls[0]};
         chains[1] = Chain{static_cast<const char*>(input_dev) + (size_t)b0 * in_bytes_per_sample, out_dev + (size_t)b0 * HMM_FEATURE_DIM,
-                          ws + p0.total, ws_plan(e, batch - b0), e->side_stream, batch - b0};
+                          ws + p0.total, ws_plan(e, batch - b0), e->side_stream, batch - b0,
+                          e->cls_stream[1], e->ev_x[1], e->ev_cls[1]};
         n_chains = 2;
         HMM_HIP_CHECK(hipEventRecord(e->ev_fork, st));                       // fork
         HMM_HIP_CHECK(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
@@ -440,6 +465,8 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
     for (int i = 0; i < e->depth && rc == HMM_OK; ++i)
         for (int c = 0; c < n_chains && rc == HMM_OK; ++c) rc = chain_block(e, chains[c], i);
     for (int c = 0; c < n_chains && rc == HMM_OK; ++c) rc = chain_head(e, chains[c]);
+    if (rc != HMM_OK)                                                        // a failed chain may have left its cls fork un-joined
+        for (int c = 0; c < 2; ++c) (void)hipStreamSynchronize(e->cls_stream[c]);
     if (n_chains == 2) {
         // join -- also when a launch failed mid-chain: whatever was queued on the side stream must be ordered before
         // the caller's stream continues (the caller may free or reuse the workspace right after an error return)

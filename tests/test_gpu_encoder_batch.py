@@ -158,3 +158,32 @@ def test_full_depth_audio_batch128_and_text_batch96_bitwise_batch_invariance():
     assert torch.equal(big, tower(tok, max_batch=16))
     _check(big[[0, 47, 48, 95]], ib.text_forward(tok[[0, 47, 48, 95]], st), scale=1.0 / 0.07,
            what="text full depth B=96")
+
+
+@pytest.mark.parametrize("batch", [6, 70])
+def test_forward_is_graph_capturable(batch):
+    """include/hippomm_hip.h: every launch goes to the caller's stream and nothing synchronises or allocates, so a forward
+    (including its internal fork / join onto the handle's own streams) can be captured into a HIP graph and replayed."""
+    from hippomm_amd.encoder import HipTower
+    spec = ib.reduced(ib.VISION_HUGE, 2)
+    st = ib.synthetic_state(spec, seed=13, init="rich")
+    tower = HipTower("vision", st, depth=2)
+    x = _frames(batch, seed=2).cuda()
+    out = torch.empty(batch, 1024, device="cuda")
+    eager = tower(x)                                   # also warms up (LDS attributes, workspace) outside the capture
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        tower.forward_into(x, out)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        tower.forward_into(x, out)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    x.copy_(_frames(batch, seed=3).cuda())             # new input, same graph
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, tower(x))
