@@ -287,8 +287,10 @@ static int split_point(const hmm_encoder* e, int batch) {
 extern "C" size_t hmm_encoder_workspace_bytes(const hmm_encoder* e, int batch) {
     if (!e || batch < 1) return 0;
     const int b0 = split_point(e, batch);
-    if (b0 == 0) return ws_plan(e, batch).total;
-    return ws_plan(e, b0).total + ws_plan(e, batch - b0).total;
+    const size_t one = ws_plan(e, batch).total;
+    if (b0 == 0) return one;
+    const size_t two = ws_plan(e, b0).total + ws_plan(e, batch - b0).total;
+    return two > one ? two : one;            // a forward under stream capture runs as one chain (see hmm_encoder_forward)
 }
 
 extern "C" double hmm_encoder_flops(const hmm_encoder* e, int batch) {
@@ -446,7 +448,14 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
 
     Chain chains[2];
     int n_chains = 1;
-    const int b0 = split_point(e, batch);
+    int b0 = split_point(e, batch);
+    {
+        // Under hipGraph stream capture the batch runs as ONE chain: capturing the two-chain fork (a forked stream that
+        // forks again for its cls projection) crashes inside the ROCm 7.0 runtime.  Embeddings are bitwise the same.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        HMM_HIP_CHECK(hipStreamIsCapturing(st, &cap));
+        if (cap != hipStreamCaptureStatusNone) b0 = 0;
+    }
     if (b0 == 0) {
         chains[0] = Chain{input_dev, out_dev, ws, ws_plan(e, batch), st, batch, e->cls_stream[0], e->ev_x[0], e->ev_cls[0]};
     } else {

@@ -12,8 +12,10 @@
  *   - plain C types only; every pointer named *_dev is a DEVICE pointer owned by the caller
  *     (PyTorch-ROCm allocates).  The library never frees or reallocates caller memory and
  *     never allocates outputs.  Only hmm_encoder_create() allocates (its own packed weights).
- *   - every launch goes to the caller's stream (hipStream_t passed as void*); no call
- *     synchronises the device, so all calls are graph-capturable.
+ *   - every launch goes to the caller's stream (hipStream_t passed as void*; hmm_encoder_forward also uses streams
+ *     owned by the handle, forked from and joined to the caller's stream with events); no call synchronises the
+ *     device or allocates, so all calls can be captured into a HIP graph (tests/test_gpu_encoder_batch.py).  A forward
+ *     issued under stream capture runs as a single chain whatever hmm_encoder_set_streams says.
  *   - return value: 0 = ok, negative = error (HMM_E_*); hmm_last_error() returns a
  *     thread-local message for the last failing call on this thread.
  *   - single-threaded use per handle, as in the reference (all call sites are on the main

@@ -160,14 +160,15 @@ def test_full_depth_audio_batch128_and_text_batch96_bitwise_batch_invariance():
            what="text full depth B=96")
 
 
-@pytest.mark.parametrize("batch", [6, 70])
-def test_forward_is_graph_capturable(batch):
+@pytest.mark.parametrize("batch,streams", [(6, 2), (70, 1), (70, 2)])
+def test_forward_is_graph_capturable(batch, streams):
     """include/hippomm_hip.h: every launch goes to the caller's stream and nothing synchronises or allocates, so a forward
     (including its internal fork / join onto the handle's own streams) can be captured into a HIP graph and replayed."""
     from hippomm_amd.encoder import HipTower
     spec = ib.reduced(ib.VISION_HUGE, 2)
     st = ib.synthetic_state(spec, seed=13, init="rich")
     tower = HipTower("vision", st, depth=2)
+    tower.set_streams(streams)
     x = _frames(batch, seed=2).cuda()
     out = torch.empty(batch, 1024, device="cuda")
     eager = tower(x)                                   # also warms up (LDS attributes, workspace) outside the capture
