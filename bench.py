@@ -523,6 +523,12 @@ def main():
                 line["torch_rocm_reference"] = torch_rocm_reference()
                 line["cpu_baseline"] = encoder_cpu_baseline(frames32)
         print(json.dumps(line), flush=True)
+        bad = [k for k in ("parity_vs_oracle",) if k in line and not line[k].get("ok", True)]
+        if "scan" in line and not line["scan"].get("parity_vs_oracle", {}).get("top32_indices_equal", True):
+            bad.append("scan.parity_vs_oracle")
+        if bad:                                            # a fast wrong answer is not a result
+            print(f"bench.py: parity check failed: {bad}", file=sys.stderr)
+            sys.exit(4)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
