@@ -37,6 +37,23 @@ def test_library_exports_nothing_but_the_header():
     assert not [n for n in exported if n.startswith(("hmm_dev_", "hmm_probe_"))]
 
 
+def test_probe_build_is_a_superset_kept_out_of_the_package():
+    """tools/libhippomm_probe.so (same sources, -DHMM_PROBE) carries the knobs; nothing under hippomm_amd/, tests/ or bench.py
+    loads it."""
+    import subprocess
+    from hippomm_amd import build
+    probe = build.build_probe()
+    out = subprocess.run(["nm", "-D", "--defined-only", str(probe)], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("hmm_")}
+    assert set(_declared_symbols()) <= exported
+    assert any(n.startswith("hmm_probe_") for n in exported)
+    for path in list((ROOT / "hippomm_amd").rglob("*.py")) + [ROOT / "bench.py", ROOT / "__graft_entry__.py"]:
+        text = path.read_text()
+        if path.name == "build.py" or path.name == "__graft_entry__.py":
+            continue                                  # they only BUILD it
+        assert "libhippomm_probe" not in text, path
+
+
 def test_binding_table_matches_header():
     from hippomm_amd import _lib
     assert sorted(_lib._SIGNATURES) == _declared_symbols()
