@@ -37,6 +37,22 @@ def scan_case(name: str):
         store /= np.linalg.norm(store, axis=1, keepdims=True)
         query = (store[17] + 0.3 * rng.standard_normal(D)).astype(np.float32)
         return query, store, 5
+    if name in ("n1000_k5_unitrows_audio20", "n2500_k5_unitrows", "n64_k5_event", "n777_k32_unitrows_f64"):
+        # more event-shaped cases (hippocampal_memory.py:3153, :3304): unit-norm vision rows / audio rows of length <= 20
+        # (mean of three 20 x unit vectors), the query a noisy copy of a stored row, k = 5; one float64 store as after
+        # load_theta_event (:391-395)
+        n = {"n1000_k5_unitrows_audio20": 1000, "n2500_k5_unitrows": 2500, "n64_k5_event": 64, "n777_k32_unitrows_f64": 777}[name]
+        rng = np.random.default_rng(1000 + n)
+        store = rng.standard_normal((n, D)).astype(np.float32)
+        store /= np.linalg.norm(store, axis=1, keepdims=True)
+        if name == "n1000_k5_unitrows_audio20":
+            others = rng.standard_normal((2, n, D)).astype(np.float32)
+            others /= np.linalg.norm(others, axis=2, keepdims=True)
+            store = ((store + 0.3 * others[0] + 0.3 * others[1]) * np.float32(20.0 / 3.0)).astype(np.float32)
+        query = (store[n // 3] + 0.25 * rng.standard_normal(D).astype(np.float32) * np.linalg.norm(store[n // 3]) / 32).astype(np.float32)
+        if name.endswith("f64"):
+            store = store.astype(np.float64)
+        return query, store, (32 if "k32" in name else 5)
     if name == "k_gt_n":
         rng = np.random.default_rng(5)
         return rng.standard_normal(D, dtype=np.float32), rng.standard_normal((7, D), dtype=np.float32), 32
@@ -59,7 +75,8 @@ def scan_case(name: str):
 
 
 SCAN_CASES = ["n4096_k5", "n4096_k32", "n4096_k32_f64store", "n300_k5_unitrows",
-              "k_gt_n", "store_1d", "duplicate_rows", "zero_row"]
+              "k_gt_n", "store_1d", "duplicate_rows", "zero_row",
+              "n1000_k5_unitrows_audio20", "n2500_k5_unitrows", "n64_k5_event", "n777_k32_unitrows_f64"]
 
 
 # ------------------------------------------------------------- select (a7)
