@@ -1,10 +1,11 @@
 """Key-frame selection (hmm_gram_select) timing at the BASELINE sizes, next to the numpy oracle on the host."""
 import sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from hippomm_amd.consolidation import select_key_frames_device
 from oracle.consolidation_oracle import select_key_frames_oracle
-sys.path.insert(0, "tests/golden")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 import recipes
 for name, n in [("n32_clusters6", 32), ("n257_clusters40", 257), ("n3600_clusters600", 3600)]:
     f, t = recipes.select_case(name)

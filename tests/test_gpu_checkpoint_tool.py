@@ -1,6 +1,7 @@
 """tools/validate_checkpoint.py on a synthetic .pth with upstream key names (there is no real imagebind_huge.pth here):
-the tool loads it through ImageBind(model_path), reports consumed / unused / missing keys per tower and the
-cosine against the fp32 oracle; a foreign key and a dropped key are reported and fail the run."""
+the tool loads it through ImageBind(model_path) and reports consumed / unused / missing keys per tower;
+tests/checkpoint_vs_oracle.py adds the cosine against the fp32 oracle; a foreign key and a dropped key are reported
+and fail the run."""
 import json
 import subprocess
 import sys
@@ -15,8 +16,8 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _run(path, *extra):
-    r = subprocess.run([sys.executable, str(ROOT / "tools" / "validate_checkpoint.py"), str(path), "--depth", "1", *extra],
+def _run(path, *extra, script=("tools", "validate_checkpoint.py")):
+    r = subprocess.run([sys.executable, str(ROOT.joinpath(*script)), str(path), "--depth", "1", *extra],
                        capture_output=True, text=True, timeout=900)
     return r.returncode, json.loads(r.stdout[r.stdout.index("{"):])
 
@@ -29,7 +30,7 @@ def test_tool_on_a_synthetic_checkpoint(tmp_path):
     sd["modality_trunks.depth.blocks.0.norm_1.weight"] = torch.ones(384)            # a modality that is not built
     good = tmp_path / "imagebind_huge.pth"
     torch.save(sd, good)
-    rc, rep = _run(good, "--oracle")
+    rc, rep = _run(good, script=("tests", "checkpoint_vs_oracle.py"))
     assert rc == 0 and rep["ok"], rep
     assert rep["modalities_in_file_not_built"] == ["depth"]
     for t in ("vision", "audio", "text"):

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Validate the towers against a REAL ImageBind checkpoint, when one is supplied.
 
-    python tools/validate_checkpoint.py /path/to/imagebind_huge.pth [--towers vision audio text] [--oracle]
+    python tools/validate_checkpoint.py /path/to/imagebind_huge.pth [--towers vision audio text]
+    python tests/checkpoint_vs_oracle.py /path/to/imagebind_huge.pth      # the same + cosine against the fp32 CPU oracle
 
 The encoder oracle (oracle/imagebind_oracle.py) and the HIP towers are restated from the published
 architecture with upstream state-dict key names ("parity unpinned": neither the imagebind package nor
@@ -13,10 +14,11 @@ This script is the hook that can retire that caveat once a checkpoint is at hand
      mismatch) and which expected keys are MISSING (hmm_encoder_load_param / hmm_encoder_missing_params);
   2. runs the tower on a few seeded inputs through ImageBind(model_path) -- the reference's own constructor
      signature -- and reports embedding norms (vision: 1; audio: <= 20; text: exp(log_logit_scale)) and finiteness;
-  3. with --oracle, runs the fp32 CPU oracle on the same weights and inputs and reports the cosine between the two
-     (tests' tolerance: >= 1 - 2e-4).
+The comparison against the fp32 CPU oracle on the same weights lives with the other test infrastructure
+(tests/checkpoint_vs_oracle.py calls validate() below and adds the cosine, tolerance >= 1 - 2e-4): nothing under
+tools/ or the package imports oracle/.
 
-Exit code 0 when every tower loads with no missing and no unused key and (with --oracle) meets the tolerance.
+Exit code 0 when every tower loads with no missing and no unused key and every embedding is finite.
 Needs a GPU.  No network access is attempted.
 """
 from __future__ import annotations
@@ -65,52 +67,55 @@ def key_report(state_dict, tower: str, depth: int = 0):
             "missing_count": int(n_missing), "missing": missing_msg}
 
 
-def main():
+def seeded_inputs(batch: int):
+    import torch
+    g = torch.Generator().manual_seed(0)
+    return {"vision": torch.randn(batch, 3, 224, 224, generator=g),
+            "audio": torch.randn(batch, 3, 1, 128, 204, generator=g),
+            "text": torch.tensor([[49406, 320, 1125, 49407] + [0] * 73] * batch)}
+
+
+def validate(checkpoint: str, towers, batch: int = 2, depth: int = 0):
+    """-> (report, ok, state_dict, inputs, embeddings of the towers that loaded cleanly)."""
+    import torch
+    from hippomm_amd.encoder import ImageBind
+    sd = torch.load(checkpoint, map_location="cpu")
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    report, ok = {"checkpoint": checkpoint, "n_keys": len(sd)}, True
+    other = sorted({k.split(".")[1] for k in sd if k.count(".") >= 2} - set(towers))
+    report["modalities_in_file_not_built"] = other            # depth / thermal / imu: not on the reference's path
+    for tower in towers:
+        report[tower] = key_report(sd, tower, depth)
+        ok &= report[tower]["missing_count"] == 0 and not report[tower]["unused"]
+    inputs = seeded_inputs(batch)
+    loadable = [t for t in towers if report[t]["missing_count"] == 0 and not report[t]["unused"]]
+    emb = {}
+    if loadable:
+        cut = {t: depth for t in loadable} if depth > 0 else None
+        model = ImageBind(checkpoint, towers=tuple(loadable), depth=cut)      # the reference's constructor argument
+        out = model.forward({t: inputs[t].cuda() for t in loadable})
+        for t in loadable:
+            emb[t] = out[t].float().cpu()
+            report[t]["embedding_norms"] = [round(float(x), 5) for x in emb[t].norm(dim=1)]
+            report[t]["finite"] = bool(torch.isfinite(emb[t]).all())
+            ok &= report[t]["finite"]
+    return report, bool(ok), sd, inputs, emb
+
+
+def parse_args(extra=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("checkpoint")
     ap.add_argument("--towers", nargs="+", default=["vision", "audio", "text"], choices=["vision", "audio", "text"])
-    ap.add_argument("--oracle", action="store_true", help="also run the fp32 CPU oracle on the same weights (slow)")
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--depth", type=int, default=0, help="testing only: cut every tower to this many blocks")
-    args = ap.parse_args()
+    return ap.parse_args(extra)
 
-    import torch
-    from hippomm_amd.encoder import ImageBind
-    sd = torch.load(args.checkpoint, map_location="cpu")
-    if isinstance(sd, dict) and "state_dict" in sd:
-        sd = sd["state_dict"]
-    report, ok = {"checkpoint": args.checkpoint, "n_keys": len(sd)}, True
-    other = sorted({k.split(".")[1] for k in sd if k.count(".") >= 2} - set(args.towers))
-    report["modalities_in_file_not_built"] = other            # depth / thermal / imu: not on the reference's path
-    for tower in args.towers:
-        report[tower] = key_report(sd, tower, args.depth)
-        ok &= report[tower]["missing_count"] == 0 and not report[tower]["unused"]
 
-    g = torch.Generator().manual_seed(0)
-    inputs = {"vision": torch.randn(args.batch, 3, 224, 224, generator=g),
-              "audio": torch.randn(args.batch, 3, 1, 128, 204, generator=g),
-              "text": torch.tensor([[49406, 320, 1125, 49407] + [0] * 73] * args.batch)}
-    towers = [t for t in args.towers if report[t]["missing_count"] == 0 and not report[t]["unused"]]   # loadable towers
-    if towers:
-        depth = {t: args.depth for t in towers} if args.depth > 0 else None
-        model = ImageBind(args.checkpoint, towers=tuple(towers), depth=depth)   # the reference's constructor argument
-        emb = model.forward({t: inputs[t].cuda() for t in towers})
-        for t in towers:
-            e = emb[t].float().cpu()
-            report[t]["embedding_norms"] = [round(float(x), 5) for x in e.norm(dim=1)]
-            report[t]["finite"] = bool(torch.isfinite(e).all())
-            ok &= report[t]["finite"]
-        if args.oracle:
-            from oracle import imagebind_oracle as ib
-            specs = {"vision": ib.VISION_HUGE, "audio": ib.AUDIO_HUGE, "text": ib.TEXT_HUGE}
-            if args.depth > 0:
-                specs = {t: ib.reduced(s, args.depth) for t, s in specs.items()}
-            want = ib.forward({t: inputs[t] for t in towers}, {t: sd for t in towers}, specs)
-            for t in towers:
-                cos = torch.nn.functional.cosine_similarity(emb[t].float().cpu(), want[t], dim=1)
-                report[t]["cos_vs_fp32_oracle"] = [round(float(c), 7) for c in cos]
-                ok &= bool((1 - cos).max() <= 2e-4)
-    report["ok"] = bool(ok)
+def main():
+    args = parse_args()
+    report, ok, _, _, _ = validate(args.checkpoint, args.towers, args.batch, args.depth)
+    report["ok"] = ok
     print(json.dumps(report, indent=1))
     sys.exit(0 if ok else 1)
 
