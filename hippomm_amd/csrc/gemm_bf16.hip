@@ -251,24 +251,22 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
         constexpr int RS = 272;
         float* C = static_cast<float*>(Cout);
         const int rsub = lane >> 4, chunk = lane & 15;
+        // Software-pipelined over the two 64-row halves: the residual rows of half 1 are requested as soon as half 0's
+        // accumulators are parked in the slab (their registers are free from then on), so they fly during half 0's
+        // read-add-store and half 1 never waits a full HBM latency (out-proj tile epilogue: 16.6 us before).
+        float4 xin[2][16];
+        auto load_resid = [&](int half) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float4 xin[16];
-            if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {       // residual reads issued first: they fly during the transpose
-#pragma unroll
-                for (int it = 0; it < 16; ++it) {
-                    const int m = m_wave + half * 64 + it * 4 + rsub;
-                    xin[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (m < M) {                                 // streamed once: non-temporal (out-proj -2 % in the tower, -12 % alone)
-                        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(C + (size_t)m * N + n_wave + chunk * 4));
-                        xin[it] = make_float4(t[0], t[1], t[2], t[3]);
-                    }
+            for (int it = 0; it < 16; ++it) {
+                const int m = m_wave + half * 64 + it * 4 + rsub;
+                xin[half][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < M) {                                     // streamed once: non-temporal (out-proj -2 % in the tower, -12 % alone)
+                    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(C + (size_t)m * N + n_wave + chunk * 4));
+                    xin[half][it] = make_float4(t[0], t[1], t[2], t[3]);
                 }
             }
-            if (half == 1) {                                      // slab is re-used: previous reads must be done
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-            }
+        };
+        auto park = [&](int half) {                              // accumulators + bias -> the wave's slab, row-major
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -279,13 +277,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+        };
+        auto drain = [&](int half) {                             // slab rows (+ residual) -> C, 256 B per 16 lanes
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int row = it * 4 + rsub;
                 float4 v = *reinterpret_cast<const float4*>(slab + row * RS + chunk * 16);
                 const int m = m_wave + half * 64 + row;
                 if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
-                    v.x += xin[it].x; v.y += xin[it].y; v.z += xin[it].z; v.w += xin[it].w;
+                    v.x += xin[half][it].x; v.y += xin[half][it].y; v.z += xin[half][it].z; v.w += xin[half][it].w;
                 }
                 if (m < M) {
                     if constexpr (EPI == HMM_EPI_BIAS_RESID_F32)
@@ -294,7 +294,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
                         *reinterpret_cast<float4*>(C + (size_t)m * N + n_wave + chunk * 4) = v;
                 }
             }
-        }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is re-used: reads must be done
+            __builtin_amdgcn_wave_barrier();
+        };
+        if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) load_resid(0);
+        park(0);
+        if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) load_resid(1);
+        drain(0);
+        park(1);
+        drain(1);
     }
 }
 
