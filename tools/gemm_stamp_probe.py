@@ -64,6 +64,14 @@ for name, N, K, epi in shapes:
     rec["epilogue_start_spread_p5_p95_us_per_round"] = spread
     ep = end - loop_done
     rec["epilogue_us_by_round_median"] = [round(float(np.median(ep[order[r * 256:(r + 1) * 256]])), 2) for r in range(rounds)]
+    # hand-over on one CU: end of a workgroup's stores -> first instruction of the next workgroup on the same CU
+    gaps, key = [], xcc.astype(np.int64) * 4096 + cu
+    for kcu in np.unique(key):
+        sel = np.where(key == kcu)[0]
+        sel = sel[np.argsort(start[sel])]
+        gaps.extend((start[sel[1:]] - end[sel[:-1]]).tolist())
+    rec["cu_handover_gap_us"] = [round(float(np.percentile(gaps, q)), 2) for q in (10, 50, 90)]
+    rec["workgroups_per_cu"] = [int(x) for x in np.percentile(np.bincount(np.unique(key, return_inverse=True)[1]), (0, 50, 100))]
     res[name] = rec
     print(name, rec, flush=True)
     del a, w, c

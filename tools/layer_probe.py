@@ -71,6 +71,9 @@ def apply(cfg):
             steps = steps_fused if v else steps_plain
             if tower is not None:
                 tower.set_fused_attention(bool(v))
+        elif k == "streams":                 # pseudo-knob: hmm_encoder_set_streams (1 = one chain, 2 = two half-batches)
+            if tower is not None:
+                tower.set_streams(v)
         else:
             setter(lib, k)(v)
 

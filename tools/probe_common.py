@@ -12,7 +12,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 def load_probe():
     from hippomm_amd import _lib as L
-    path = os.path.join(ROOT, "tools", "libhippomm_probe.so")
+    path = os.environ.get("HMM_PROBE_LIB") or os.path.join(ROOT, "tools", "libhippomm_probe.so")   # override: A/B of two builds
     if not os.path.exists(path):
         raise SystemExit(f"{path} missing: python -m hippomm_amd.build --probe")
     L._lib = L.bind(path)          # every later _lib.load() in this process returns the probe build
