@@ -14,6 +14,7 @@
 // Keys are 64-bit: (order_bits(sim) << 32) | row, so "larger key" == "better, higher row first
 // on ties, NaN first"; 0 is the padding key (no valid row maps to it).
 #include "hmm_common.h"
+#include "topk_tournament.h"
 
 namespace hmm {
 
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const float4* __restrict
             const int n2 = pow2_at_least(n, 64);
             for (int t = n + threadIdx.x; t < n2; t += 256) cand[t] = 0ull;
             __syncthreads();
-            bitonic_sort_desc_rt(cand, n2);
+            if (k <= 64) top64_desc(cand, n2);                          // block-uniform; leaves cand[0..63] sorted
+            else         bitonic_sort_desc_rt(cand, n2);
             if (threadIdx.x == 0) count = n < k ? n : k;
             __syncthreads();
         }
@@ -222,8 +224,8 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const float4* __restrict
 // at cand[b*k ..].  The global top-k can only contain keys of the k blocks with the largest maxima: a key
 // below the k-th largest block maximum has k better keys (those maxima) ahead of it.  One workgroup sorts
 // the block maxima, gathers the k*k keys of the winning blocks, sorts them and decodes the best k.
-// Replaces two chunk-sort passes and the decode launch (~56 us -> 37 us in the rocprofv3 trace at N=1M, k=32: 66 + 55
-// bitonic stages of 1024 threads; 5 % of a query).
+// Replaces two chunk-sort passes and the decode launch.  Both selections are best-64 tournaments (topk_tournament.h):
+// full bitonic sorts here were 66 + 55 barrier-separated stages of 1024 threads, 36 us = 5.5 % of a 1M-row query.
 __global__ __launch_bounds__(1024) void topk_final_kernel(const uint64_t* __restrict__ cand, int n_blocks, int k,
                                                           int64_t n_waves, uint64_t* __restrict__ keys_out, int k_pad,
                                                           int64_t* __restrict__ idx_out, float* __restrict__ sim_out,
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const uint64_t* __rest
     const int n2 = pow2_at_least(n_blocks, 64);
     for (int t = tid; t < n2; t += 1024) mx[t] = t < n_blocks ? cand[(int64_t)t * k] : 0ull;
     __syncthreads();
-    bitonic_sort_desc_rt(mx, n2);
+    top64_desc(mx, n2);                        // k <= 64 here (k*k <= kChunk)
     // mx[0..k) = the k largest maxima; recover their blocks from the row index (row r belongs to wave
     // (r/2) % n_waves, 4 waves per block) and gather those blocks' lists
     const int n_win = n_blocks < k ? n_blocks : k;
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const uint64_t* __rest
         s[t] = key;
     }
     __syncthreads();
-    bitonic_sort_desc_rt(s, m2);
+    top64_desc(s, m2);
     if (keys_out != nullptr) {
         for (int t = tid; t < k_pad; t += 1024) keys_out[t] = t < k ? s[t] : 0ull;
     } else {

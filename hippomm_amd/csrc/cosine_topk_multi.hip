@@ -28,6 +28,7 @@
 // exactly as topk_final_kernel does: the global top-k lies in the lists of the k workgroups with the largest maxima.
 // Keys, total order (NaN first, higher row first on ties) and outputs are those of hmm_cosine_topk.
 #include "hmm_common.h"
+#include "topk_tournament.h"
 
 namespace hmm {
 
@@ -272,16 +273,7 @@ __global__ __launch_bounds__(1024) void topk_final_multi_kernel(const uint64_t* 
     while (n2 < n_blocks) n2 <<= 1;
     for (int t = tid; t < n2; t += 1024) mx[t] = t < n_blocks ? c[(size_t)t * k] : 0ull;
     __syncthreads();
-    for (int kk = 2; kk <= n2; kk <<= 1)
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (n2 >> 1); t += 1024) {
-                const int i = 2 * t - (t & (j - 1)), l = i + j;
-                const bool desc = (i & kk) == 0;
-                const uint64_t a = mx[i], b = mx[l];
-                if ((a < b) == desc) { mx[i] = b; mx[l] = a; }
-            }
-            __syncthreads();
-        }
+    top64_desc(mx, n2);                                      // k <= kMMaxK = 64: the best 64 maxima are enough
     const int n_win = n_blocks < k ? n_blocks : k;
     int m2 = 64;
     while (m2 < n_win * k) m2 <<= 1;
@@ -298,16 +290,7 @@ __global__ __launch_bounds__(1024) void topk_final_multi_kernel(const uint64_t* 
         s[t] = key;
     }
     __syncthreads();
-    for (int kk = 2; kk <= m2; kk <<= 1)
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (m2 >> 1); t += 1024) {
-                const int i = 2 * t - (t & (j - 1)), l = i + j;
-                const bool desc = (i & kk) == 0;
-                const uint64_t a = s[i], b = s[l];
-                if ((a < b) == desc) { s[i] = b; s[l] = a; }
-            }
-            __syncthreads();
-        }
+    top64_desc(s, m2);
     if (tid == 0 && n_out) n_out[qi] = k_eff;
     for (int t = tid; t < k_eff; t += 1024) {
         idx_out[(size_t)qi * k_stride + t] = (int64_t)(s[t] & 0xFFFFFFFFull);
