@@ -366,7 +366,8 @@ __global__ __launch_bounds__(1024) void segment_topk_kernel(const float* __restr
             s[t] = key;
         }
         __syncthreads();
-        bitonic_sort_desc_rt(s, n2);
+        if (k <= 64) top64_desc(s, n2);                        // best-64 tournament: s[0..63] sorted, the rest clobbered
+        else         bitonic_sort_desc_rt(s, n2);
         have = total < k ? total : k;
         base += take;
     } while (base < n);
