@@ -90,7 +90,6 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
                 *reinterpret_cast<uint4*>(v_lds + row * C::VROW + c * 16) = vv[i];
             }
         }
-        attention_v_ones<DH, NKT>(v_lds);
         __syncthreads();
         if (bias_k != nullptr && tid < DH) {             // the add_bias_kv position: row T
             *reinterpret_cast<bf16_t*>(k_lds + T * C::KROW + tid * 2) = (bf16_t)bias_k[h * DH + tid];

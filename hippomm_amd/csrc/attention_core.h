@@ -34,12 +34,6 @@ struct AttnCfg {
     static constexpr int X_FLOATS = DH + 2;         // cooperative extra-query partial: O[DH], m, l
     static constexpr int X_BYTES = (NKT * X_FLOATS * 4 + 15) / 16 * 16;
     static constexpr int LDS = K_BYTES + V_BYTES + X_BYTES;
-    // Softmax denominators from the matrix cores: when the last d tile of O^T has spare rows (dh = 80: rows 16..31 of
-    // tile 2), the V image carries 1.0 in columns DH and DH + 4 of every key row, so O^T rows DH / DH + 4 -- accumulator
-    // register L_REG of the last tile in lane halves 0 / 1 -- accumulate sum_k P[k]: the row sum of the bf16 weights that
-    // are actually applied, rescaled with O by the online softmax.  Saves one VALU add per score.
-    static constexpr bool ONES = (DH % 32) != 0 && (DH % 8) == 0 && (DH % 32) + 8 <= 32;
-    static constexpr int L_REG = 4 * ((DH % 32) / 8);
     static constexpr int CH = 3;                    // key tiles per online-softmax chunk
     static constexpr int NCH = (NKT + CH - 1) / CH;
     static_assert(DT * 64 <= VROW, "V row must cover every d tile a tr-read touches");
@@ -47,19 +41,7 @@ struct AttnCfg {
 
 constexpr int kAttnWaves = 8;
 
-// Writes the 1.0 columns of the V image (AttnCfg::ONES); call before the barrier that publishes the image.
-template <int DH, int NKT>
-__device__ __forceinline__ void attention_v_ones(char* v_lds) {
-    using C = AttnCfg<DH, NKT>;
-    if constexpr (C::ONES) {
-        for (int row = threadIdx.x; row < C::NKEY; row += blockDim.x) {
-            *reinterpret_cast<bf16_t*>(v_lds + row * C::VROW + DH * 2) = (bf16_t)1.0f;
-            *reinterpret_cast<bf16_t*>(v_lds + row * C::VROW + (DH + 4) * 2) = (bf16_t)1.0f;
-        }
-    }
-}
-
-// k_lds / v_lds: the images (rows >= Lk zero-filled; attention_v_ones applied); part: C::X_BYTES of LDS scratch; load_q(row, ks) -> the bf16x8
+// k_lds / v_lds: the images (rows >= Lk zero-filled); part: C::X_BYTES of LDS scratch; load_q(row, ks) -> the bf16x8
 // fragment d = 16 ks + 8 hh .. + 7 of query `row` (row < T) for this lane's hh = lane >> 5; qf: the fragments of query
 // tile `wave`, preloaded by the caller; out_head = out + sample * T * D + head * DH.  Ends with the results stored.
 template <int DH, int NKT, class QLoad>
@@ -153,7 +135,7 @@ __device__ __forceinline__ void attention_core(const char* k_lds, const char* v_
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
             const float neg_m = -m_new * scale_log2e;
             m_run = m_new;
-            if constexpr (!C::ONES) l_run *= alpha;
+            l_run *= alpha;
 #pragma unroll
             for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
@@ -163,13 +145,10 @@ __device__ __forceinline__ void attention_core(const char* k_lds, const char* v_
                 const int kt = ch * CHT + i;
                 if (kt < NKT) {
 #pragma unroll
-                    for (int reg = 0; reg < 16; reg += 2) {      // v_pk_fma_f32: two exponents per instruction
-                        typedef float f32x2 __attribute__((ext_vector_type(2)));
-                        const f32x2 e = __builtin_elementwise_fma(f32x2{s[i][reg], s[i][reg + 1]}, f32x2{scale_log2e, scale_log2e},
-                                                                  f32x2{neg_m, neg_m});
-                        const float p0 = __builtin_amdgcn_exp2f(e[0]), p1 = __builtin_amdgcn_exp2f(e[1]);
-                        s[i][reg] = p0; s[i][reg + 1] = p1;
-                        if constexpr (!C::ONES) l_run += p0 + p1;
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(s[i][reg], scale_log2e, neg_m));
+                        s[i][reg] = p;
+                        l_run += p;
                     }
                 }
             }
@@ -200,9 +179,7 @@ __device__ __forceinline__ void attention_core(const char* k_lds, const char* v_
 
         // A lane holds 4 consecutive d (8 B) per accumulator group and its partner lane^32 the next 4;
         // v_permlane32_swap pairs two groups so that every lane stores 16 B (half the store instructions, 32-B pieces).
-        float l;
-        if constexpr (C::ONES) l = o[C::DT - 1][C::L_REG];       // both lane halves hold the full row sum
-        else                   l = l_run + __shfl_xor(l_run, 32, 64);
+        const float l = l_run + __shfl_xor(l_run, 32, 64);
         const float inv_l = 1.0f / l;
         bf16_t* op = out_head + (size_t)(qrow < T ? qrow : T - 1) * D + 8 * hh;
 #pragma unroll
@@ -251,7 +228,7 @@ __device__ __forceinline__ void attention_core(const char* k_lds, const char* v_
                 sx[reg] = pv;
                 lw += pv;
             }
-            if constexpr (!C::ONES) lw += __shfl_xor(lw, 32, 64);
+            lw += __shfl_xor(lw, 32, 64);
             f32x16 ox[C::DT];
 #pragma unroll
             for (int dt = 0; dt < C::DT; ++dt) ox[dt] = f32x16{};
@@ -281,7 +258,6 @@ __device__ __forceinline__ void attention_core(const char* k_lds, const char* v_
                             dst[d0 + 2] = ox[dt][4 * gq + 2]; dst[d0 + 3] = ox[dt][4 * gq + 3];
                         }
                     }
-                if constexpr (C::ONES) lw = ox[C::DT - 1][C::L_REG];       // same definition as the main tiles
                 if (hh == 0) { dst[DH] = mw; dst[DH + 1] = lw; }
             }
         }

@@ -110,7 +110,6 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
             *reinterpret_cast<uint4*>(k_lds + row * FusedCfg::KROW + c * 16) = make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint4*>(v_lds + row * FusedCfg::VROW + c * 16) = make_uint4(0u, 0u, 0u, 0u);
         }
-        attention_v_ones<kFDH, kFNKT>(v_lds);
     }
     __syncthreads();
 
