@@ -64,6 +64,22 @@ while time.perf_counter() - t0 < 2.0:
         lib.hmm_op_layernorm_bf16(a.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), 65792, 1280, 1e-6, L.stream_ptr())
     torch.cuda.synchronize()
 marks.append(("layernorm", time.perf_counter()))
+del a, y
+# the whole ViT-H forward at 256 frames: two half-batch chains (the shipped default) and one chain
+from hippomm_amd.encoder import HipTower, synthetic_state_dict
+tower = HipTower("vision", synthetic_state_dict(("vision",), seed=1234))
+frames = torch.randn(256, 3, 224, 224, device="cuda"); emb = torch.empty(256, 1024, device="cuda")
+for streams in (2, 1):
+    tower.set_streams(streams)
+    time.sleep(0.5); marks.append((f"idle{streams}", time.perf_counter()))
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < 4.0:
+        for _ in range(5):
+            tower.forward_into(frames, emb)
+        torch.cuda.synchronize(); n += 5
+    dt = time.perf_counter() - t0
+    print(f"forward, {streams} stream(s): {dt / n * 1e3:.2f} ms per 256 frames", flush=True)
+    marks.append((f"forward_{streams}s", time.perf_counter()))
 stop = True; t.join()
 prev = samples[0][0]
 for name, tm in marks:
