@@ -1,6 +1,6 @@
 """Time the bf16 GEMM tile variants on the four ViT-H shapes at B=256 (M=65792)."""
 import ctypes as C, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from hippomm_amd import _lib as L
 lib = L.load()

@@ -1,6 +1,6 @@
 """Device vs host vision preprocessing on 1080p frames."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np, torch
 from PIL import Image
 from hippomm_amd import preprocess as pp

@@ -1,6 +1,6 @@
 """Per-event scan throughput: 1M rows in 2000 events of 500 frames, k=5 (the reference's per-event k)."""
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from hippomm_amd.vector_ops import FeatureStore
 n, E, k = 1_000_000, 2000, 5

@@ -1,6 +1,6 @@
 """Encoder latency at the reference's call sizes (32-frame buffer, single segments), eager vs HIP graph."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from hippomm_amd.encoder import HipTower, synthetic_state_dict
 sd = synthetic_state_dict(("vision",))

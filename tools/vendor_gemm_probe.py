@@ -2,7 +2,7 @@
 bf16 inputs, fp32 accumulate, bf16 output, no bias / activation / residual epilogue -- next to gemm_bf16 with its fused
 epilogues on the same shapes."""
 import ctypes as C, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from hippomm_amd import _lib as L
 lib = L.load()
