@@ -70,8 +70,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float*
                 for (int ni = 0; ni < NI; ++ni) {
                     const float4 x = xin[mi & 1][ni];
                     const f32x4 v = acc[mi][ni];
+                    // (accumulator + bias) + residual: the order of the ping-pong kernel's epilogue, so that a row gets the
+                    // same bits from every tile geometry
                     *reinterpret_cast<float4*>(C + (size_t)m * N + n_lane + ni * 16) =
-                        make_float4(x.x + v[0] + bv[ni].x, x.y + v[1] + bv[ni].y, x.z + v[2] + bv[ni].z, x.w + v[3] + bv[ni].w);
+                        make_float4((v[0] + bv[ni].x) + x.x, (v[1] + bv[ni].y) + x.y, (v[2] + bv[ni].z) + x.z, (v[3] + bv[ni].w) + x.w);
                 }
             }
         }

@@ -50,6 +50,29 @@ def test_gemm_bias_bf16(variant, M, N, K):
     assert torch.isnan(c[M:].float()).all(), "rows past M were written"
 
 
+def test_gemm_epilogues_bitwise_equal_across_tile_geometries():
+    """A row must get the same bits whichever tile geometry computes it (the tower picks the geometry by batch size and peels
+    the last row tile into 128x128 tiles): same K order in every main loop and the same sum order in every epilogue --
+    (accumulator + bias) + residual -- checked with a non-zero bias and residual."""
+    L, lib = _lib()
+    M, N, K = 1000, 1280, 1280
+    g = torch.Generator().manual_seed(77)
+    a = _bf16(torch.randn(M, K, generator=g)).cuda()
+    w = _bf16(torch.randn(N, K, generator=g) * 0.05).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    c0 = (torch.randn(M, N, generator=g) * 3.0).cuda()
+    for epi, dtype in ((EPI_BIAS_RESID_F32, torch.float32), (EPI_BIAS_GELU_BF16, torch.bfloat16), (EPI_BIAS_BF16, torch.bfloat16),
+                       (EPI_F32, torch.float32)):
+        outs = []
+        for variant in (0, 1, 2, 3, 4):
+            c = c0.clone().to(dtype)
+            L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K, epi, variant,
+                                              L.stream_ptr()), "gemm")
+            outs.append(c)
+        for v, o in enumerate(outs[1:], 1):
+            assert torch.equal(o, outs[0]), f"epilogue {epi}: tile geometry {v} differs from 128x128"
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_gemm_gelu_resid_f32_epilogues(variant):
     L, lib = _lib()
