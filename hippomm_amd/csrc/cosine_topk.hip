@@ -59,29 +59,36 @@ __global__ __launch_bounds__(256) void scan_sims_kernel(const float4* __restrict
     }
     const float q_len = sqrtf(wave_sum(qs));
 
-    for (int64_t r = wave * 2; r < n_rows; r += n_waves * 2) {
-        const bool two = (r + 1) < n_rows;                  // wave-uniform
-        const float4* p0 = store + r * 256 + lane;
-        const float4* p1 = p0 + (two ? 256 : 0);
-        float4 a[4], b[4];
+    // A wave takes 32 consecutive rows at a time (16 pairs) and writes their 32 similarities as ONE 128-byte line: with
+    // rows dealt pair by pair, every line of `sims` was assembled from 4-byte stores of 16 different waves (partial-line
+    // writes; the kernel ran 7 % behind the list-keeping scan kernel that stores nothing in its loop).
+    for (int64_t base = wave * 32; base < n_rows; base += n_waves * 32) {
+        float mine = 0.f;                                   // lane l < 32 ends up with the similarity of row base + l
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int64_t r = base + 2 * j;
+            if (r >= n_rows) break;                         // wave-uniform
+            const bool two = (r + 1) < n_rows;
+            const float4* p0 = store + r * 256 + lane;
+            const float4* p1 = p0 + (two ? 256 : 0);
+            float4 a[4], b[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = ld16<NT>(p0 + j * 64);
+            for (int i = 0; i < 4; ++i) a[i] = ld16<NT>(p0 + i * 64);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = ld16<NT>(p1 + j * 64);
-        float d0 = 0.f, s0 = 0.f, d1 = 0.f, s1 = 0.f;
+            for (int i = 0; i < 4; ++i) b[i] = ld16<NT>(p1 + i * 64);
+            float d0 = 0.f, s0 = 0.f, d1 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fma4(d0, s0, a[j], q[j]);
+            for (int i = 0; i < 4; ++i) fma4(d0, s0, a[i], q[i]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fma4(d1, s1, b[j], q[j]);
-        d0 = wave_sum(d0); s0 = wave_sum(s0);
-        d1 = wave_sum(d1); s1 = wave_sum(s1);
-        if (lane == 0) {
-            sims[r] = d0 / (sqrtf(s0) * q_len);
-            if (two) sims[r + 1] = d1 / (sqrtf(s1) * q_len);
+            for (int i = 0; i < 4; ++i) fma4(d1, s1, b[i], q[i]);
+            d0 = wave_sum(d0); s0 = wave_sum(s0);
+            d1 = wave_sum(d1); s1 = wave_sum(s1);
+            const float v0 = d0 / (sqrtf(s0) * q_len), v1 = d1 / (sqrtf(s1) * q_len);
+            mine = lane == 2 * j ? v0 : (lane == 2 * j + 1 ? v1 : mine);
         }
+        if (lane < 32 && base + lane < n_rows) sims[base + lane] = mine;
     }
 }
-
 
 // Descending bitonic sort of N keys in LDS by NT threads.
 template <int N, int NT>
