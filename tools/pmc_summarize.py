@@ -77,6 +77,22 @@ json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE --
                       "(separate passes)",
            "correction": "gfx950: FETCH_SIZE x2 for wide coalesced reads; KB units; fabric requests, Infinity-Cache hits included",
            "kernels": traffic}, open(prefix + "_traffic_pmc_all.json", "w"), indent=1)
+# --- LDS bank conflicts (optional fourth pass: lds/ with --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE)
+lds = load("lds")
+if lds:
+    rows_out = []
+    for (name, grid), c in sorted(lds.items()):
+        tag = short(name)
+        if tag is None or "SQ_LDS_IDX_ACTIVE" not in c:
+            continue
+        conf, act = mean(c.get("SQ_LDS_BANK_CONFLICT", [0.0])), mean(c["SQ_LDS_IDX_ACTIVE"])
+        rows_out.append({"kernel": tag, "full_name": name[:120], "grid_threads": grid, "SQ_LDS_BANK_CONFLICT": conf,
+                         "SQ_LDS_IDX_ACTIVE": act, "conflict_share_of_lds_cycles": round(conf / act, 4) if act else None})
+    json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -- python3 "
+                          "tools/pmc_workload.py",
+               "definition": "SQ_LDS_BANK_CONFLICT = extra LDS cycles spent on bank conflicts, SQ_LDS_IDX_ACTIVE = all LDS-array "
+                             "cycles (MI355X_MICROARCH.md); their ratio per kernel",
+               "kernels": rows_out}, open(prefix + "_lds_pmc_summary.json", "w"), indent=1)
 # the two files bench.py reads (kernel name + traffic_bytes_per_launch)
 def pick(tag, grid_min=0):
     c = [t for t in traffic if t["kernel"] == tag and t["grid_threads"] >= grid_min]
