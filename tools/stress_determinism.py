@@ -1,0 +1,62 @@
+"""Soak test: the same inputs must give the same bits every time, and the scan must agree with a torch reference ranking.
+  * 200 ViT-H forwards at 256 frames (two-stream path), each compared bitwise with the first;
+  * 1500 single-query scans, 300 batched (16-query) scans and 300 per-event scans over a 1M x 1024 store, every result
+    compared bitwise with the first run of the same query; 64 of the queries also against torch.topk on fp64 similarities.
+usage: stress_determinism.py [minutes]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from hippomm_amd.encoder import HipTower, synthetic_state_dict
+from hippomm_amd.vector_ops import FeatureStore
+
+budget_s = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 120.0
+t_end = time.time() + budget_s
+tower = HipTower("vision", synthetic_state_dict(("vision",), seed=1234))
+x = torch.randn(256, 3, 224, 224, device="cuda")
+ref = tower(x).clone()
+n_fwd = 0
+while time.time() < t_end - budget_s * 0.5 and n_fwd < 200:
+    out = tower(x)
+    assert torch.equal(out, ref), f"forward {n_fwd} differs from the first one"
+    n_fwd += 1
+print(f"{n_fwd} forwards bitwise equal", flush=True)
+del tower, x
+torch.cuda.empty_cache()
+
+n = 1_000_000
+rows = torch.randn(n, 1024, device="cuda")
+store = FeatureStore(rows)
+g = torch.Generator(device="cuda").manual_seed(5)
+queries = torch.randn(64, 1024, device="cuda", generator=g)
+first = {}
+checked = 0
+it = 0
+seg = torch.arange(0, n + 1, 500, device="cuda", dtype=torch.int64)
+while time.time() < t_end and it < 1500:
+    qi = it % 64
+    idx, sims = store.search_device(queries[qi], 32)
+    key = ("s", qi)
+    if key not in first:
+        first[key] = (idx.clone(), sims.clone())
+        d = (rows.double() @ queries[qi].double()) / (rows.double().norm(dim=1) * queries[qi].double().norm())
+        want = torch.topk(d, 33)
+        # exact order wherever the fp64 gaps are above the fp32 noise
+        gaps = (want.values[:-1] - want.values[1:])[:32]
+        ok = gaps > 2e-6
+        assert torch.equal(idx[ok], want.indices[:32][ok]), f"query {qi}: ranking differs from fp64 where it is separated"
+        checked += 1
+    else:
+        assert torch.equal(idx, first[key][0]) and torch.equal(sims, first[key][1]), f"scan {it} differs run to run"
+    if it % 5 == 0:
+        q16 = queries[(qi // 16) * 16:(qi // 16) * 16 + 16]
+        res = store.search_multi_device(q16, 32) if hasattr(store, "search_multi_device") else None
+        if res is not None:
+            key = ("m", qi // 16)
+            if key not in first: first[key] = tuple(t.clone() for t in res[:2])
+            else: assert all(torch.equal(a, b) for a, b in zip(res[:2], first[key])), f"batched scan {it} differs run to run"
+        r = store.search_segments_device(queries[qi], seg, 5)
+        key = ("e", qi)
+        if key not in first: first[key] = tuple(t.clone() for t in r[:2])
+        else: assert all(torch.equal(a, b) for a, b in zip(r[:2], first[key])), f"per-event scan {it} differs run to run"
+    it += 1
+print(f"{it} scans bitwise repeatable, {checked} checked against fp64 rankings", flush=True)
