@@ -64,10 +64,10 @@ __global__ __launch_bounds__(256) void scan_sims_kernel(const float4* __restrict
     // writes; the kernel ran 7 % behind the list-keeping scan kernel that stores nothing in its loop).
     for (int64_t base = wave * 32; base < n_rows; base += n_waves * 32) {
         float mine = 0.f;                                   // lane l < 32 ends up with the similarity of row base + l
-#pragma unroll 4
-        for (int j = 0; j < 16; ++j) {
+        const int64_t left = n_rows - base;
+        const int pairs = left >= 32 ? 16 : (int)((left + 1) >> 1);      // wave-uniform
+        for (int j = 0; j < pairs; ++j) {
             const int64_t r = base + 2 * j;
-            if (r >= n_rows) break;                         // wave-uniform
             const bool two = (r + 1) < n_rows;
             const float4* p0 = store + r * 256 + lane;
             const float4* p1 = p0 + (two ? 256 : 0);
