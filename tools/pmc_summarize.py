@@ -46,7 +46,7 @@ out = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BU
        "definition": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs): share of SIMD-cycles with the "
                      "matrix pipe busy while the GPU was active (GRBM_GUI_ACTIVE is summed over the 8 XCDs; the counter adds 16 "
                      "cycles per v_mfma_f32_16x16x32_bf16, 32 per 32x32x16 / f32 16x16x4).  clock_GHz = GRBM_GUI_ACTIVE / 8 / kernel "
-                     "time: the chip lowers its clock under MFMA load, so mfma_busy_over_peak_at_2p4GHz (the fraction of the 2.5 PF/s "
+                     "time: the board runs these kernels at its power cap and the clock gives way, so mfma_busy_over_peak_at_2p4GHz (the fraction of the 2.5 PF/s "
                      "dense peak the matrix pipes were kept busy for) = mfma_util x clock / 2.4.  Profiled passes run a few % slower "
                      "than unprofiled ones.",
        "kernels": []}
