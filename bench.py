@@ -56,6 +56,10 @@ FRAMES_PER_GPU = 256           # cfg2
 CFG5_FRAMES = 3600             # cfg5: one hour at 1 fps
 SCENE_LEN = 6                  # frames per synthetic scene
 SCAN_ROWS, SCAN_K = 1_000_000, 32
+# Rehearsal of the N > 1 code path on a box with fewer GPUs (HMM_BENCH_REHEARSAL=1): every rank uses cuda:0 and the
+# collectives run over gloo.  Exercises launch, sharding, gathers, merges and the JSON line -- NOT RCCL, and the
+# numbers are meaningless (the ranks share one GPU); the line says so and is never a result.
+REHEARSAL = os.environ.get("HMM_BENCH_REHEARSAL") == "1"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -64,7 +68,7 @@ SCAN_ROWS, SCAN_K = 1_000_000, 32
 def launch_ranks(n: int, argv) -> int:
     """Parent of a self-launched multi-GPU run.  Must not initialise the GPU: device_count() does not."""
     visible = torch.cuda.device_count()
-    if visible < n:
+    if visible < n and not REHEARSAL:
         print(f"bench.py: --gpus {n} but only {visible} GPU(s) visible", file=sys.stderr)
         return 3
     port = 29500 + os.getpid() % 2000
@@ -392,6 +396,48 @@ def torch_rocm_reference():
     return out
 
 
+def sharded_scan_bench(rank, world, reduce_max):
+    """The 1M x 1024 scan at N GPUs (north_star: both metrics at 1 / 2 / 4 / 8 GPUs).  The store is row-sharded
+    (hippomm_amd.sharding.sharded_top_k): every rank scans its shard, ONE all-gather of k packed keys (8 k bytes)
+    and of the row offsets per query, the same merge on every rank.  Two shapes: 1M rows per GPU (weak; the aggregate
+    GB/s is the figure that scales) and 1M rows in all (strong; latency-bound from a few GPUs on).  Every rank calls this."""
+    from hippomm_amd.sharding import sharded_top_k
+    from hippomm_amd.vector_ops import FeatureStore
+    q = torch.randn(1024, generator=torch.Generator(device="cuda").manual_seed(43), device="cuda")
+    out = {"metric": "cosine-scan GB/s over a row-sharded store (feature_search, 1024-d fp32 rows, top-32, 1 query)",
+           "unit": "GB/s", "exchange": "all-gather of 32 packed keys + 1 row offset per rank, merge on every rank"}
+    for tag, n_local in (("weak_1M_rows_per_gpu", SCAN_ROWS), ("strong_1M_rows_total", SCAN_ROWS // world)):
+        g = torch.Generator(device="cuda").manual_seed(1000 + rank)
+        rows = torch.empty(n_local, 1024, dtype=torch.float32, device="cuda")
+        for s in range(0, n_local, 125_000):
+            blk = torch.randn(min(125_000, n_local - s), 1024, generator=g, device="cuda")
+            rows[s:s + blk.shape[0]] = blk / blk.norm(dim=1, keepdim=True)
+        store = FeatureStore(rows)
+        offset = rank * n_local
+        query = lambda: sharded_top_k(q, SCAN_K, n_local, offset, store.search_keys_device)
+        idx, sims = query()
+        # parity: torch ranks every shard, the candidates are gathered, and the global order must agree wherever it is separated
+        local = torch.topk((rows @ q) / (rows.norm(dim=1) * q.norm()), SCAN_K + 1)
+        cand_v = [torch.empty_like(local.values) for _ in range(world)]
+        cand_i = [torch.empty_like(local.indices) for _ in range(world)]
+        dist.all_gather(cand_v, local.values.contiguous())
+        dist.all_gather(cand_i, (local.indices + offset).contiguous())
+        best = torch.topk(torch.cat(cand_v), SCAN_K + 1)
+        want = torch.cat(cand_i)[best.indices]
+        separated = (best.values[:-1] - best.values[1:])[:SCAN_K] > 2e-6
+        ok = bool(idx.numel() == SCAN_K and torch.equal(idx[separated], want[:SCAN_K][separated]))
+        dist.barrier()
+        ms = reduce_max(event_time_ms(query, 20, warmup=3))
+        total = float(n_local) * world * 4096.0
+        out[tag] = {"rows_per_gpu": n_local, "ms_per_query": round(ms, 4), "GBps_all_gpus": round(total / ms / 1e6, 1),
+                    "frac_of_n_gpus_x_8TBps": round(total / ms / 1e6 / (PEAK_HBM_GBS * world), 4),
+                    "indices_match_torch_where_separated": ok}
+        del rows, store, local
+        torch.cuda.empty_cache()
+    out["value"] = out["weak_1M_rows_per_gpu"]["GBps_all_gpus"]
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -417,7 +463,11 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong N",
               file=sys.stderr)
         sys.exit(2)
-    if world > 1:
+    if world > 1 and REHEARSAL:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
@@ -466,8 +516,14 @@ def main():
                                          (dist.barrier if world > 1 else (lambda: None)), reduce_max)
 
     gather_ms = None
+    sharded_scan = None
     if world > 1:                                              # the exchange step alone
         gather_ms = reduce_max(event_time_ms(lambda: all_gather_embeddings(emb, counts), 20, warmup=3))
+        if not args.no_scan:
+            try:                                               # the same code on every rank: a failure is a failure on all of them
+                sharded_scan = sharded_scan_bench(rank, world, reduce_max)
+            except Exception as exc:                           # the encoder line must survive a problem in the scan leg
+                sharded_scan = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         value = n_total * args.steps / elapsed
@@ -508,6 +564,10 @@ def main():
         line["step_tflops_executed"] = round(enc_flops_exec * args.steps / elapsed / 1e12, 1)
         roof, table = gemm_roofline(FRAMES_PER_GPU)
         line["roofline"], line["kernels"] = roof, table
+        if sharded_scan is not None:
+            line["scan"] = sharded_scan
+        if REHEARSAL:
+            line["rehearsal"] = "HMM_BENCH_REHEARSAL=1: all ranks on cuda:0 over gloo -- code-path check only, NOT a measurement"
         if extras:
             if sd is not None:
                 line["parity_vs_oracle"] = encoder_parity(sd, frames, emb)
@@ -526,6 +586,9 @@ def main():
         bad = [k for k in ("parity_vs_oracle",) if k in line and not line[k].get("ok", True)]
         if "scan" in line and not line["scan"].get("parity_vs_oracle", {}).get("top32_indices_equal", True):
             bad.append("scan.parity_vs_oracle")
+        for tag in ("weak_1M_rows_per_gpu", "strong_1M_rows_total"):
+            if "scan" in line and not line["scan"].get(tag, {}).get("indices_match_torch_where_separated", True):
+                bad.append(f"scan.{tag}")
         if bad:                                            # a fast wrong answer is not a result
             print(f"bench.py: parity check failed: {bad}", file=sys.stderr)
             sys.exit(4)
