@@ -1,0 +1,47 @@
+"""The oracle against the UNMODIFIED reference on 120 seeded random cases, live (build container only: /root/reference
+does not travel, so the test skips where it is absent -- the committed goldens of tests/golden/ are the portable pin).
+hippomm/utils/vector_ops.py:151-188 and hippomm/core/hippocampal_memory.py:944-967 run in a subprocess
+(tests/golden/live_reference.py); the oracle runs here on the same inputs, rebuilt from the same seeds."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE / "golden"))
+import live_cases  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not Path("/root/reference/hippomm").is_dir(), reason="/root/reference not present")
+
+
+@pytest.fixture(scope="module")
+def reference_results():
+    r = subprocess.run([sys.executable, str(HERE / "golden" / "live_reference.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout[r.stdout.index("{"):])
+
+
+@pytest.mark.filterwarnings("ignore:invalid value encountered")      # zero rows: 0/0 -> NaN, as in the reference
+def test_scan_oracle_equals_reference(reference_results):
+    from oracle.vector_ops_oracle import top_k_cosine_similarity_oracle
+    for seed, ref in enumerate(reference_results["scan"]):
+        q, store, k = live_cases.scan_case(seed)
+        idx, sims = top_k_cosine_similarity_oracle(q, store, k)
+        want = np.array([np.nan if s is None else s for s in ref["sims"]], dtype=np.float64)
+        assert [int(i) for i in idx] == ref["idx"], f"scan case {seed}: indices"
+        assert str(np.asarray(sims).dtype) == ref["dtype"], f"scan case {seed}: result dtype"
+        np.testing.assert_array_equal(np.asarray(sims, dtype=np.float64), want, err_msg=f"scan case {seed}: similarities")
+
+
+def test_select_oracle_equals_reference(reference_results):
+    from oracle.consolidation_oracle import select_key_frames_oracle
+    dropped = 0
+    for seed, ref in enumerate(reference_results["select"]):
+        f, t, thr = live_cases.select_case(seed)
+        kept = select_key_frames_oracle(f, t, thr)
+        assert [int(i) for i in kept] == ref, f"select case {seed}"
+        dropped += f.shape[0] - len(ref)
+    assert dropped > 1000                                   # the cases do exercise the rule
