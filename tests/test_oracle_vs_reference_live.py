@@ -1,5 +1,5 @@
-"""The oracle against the UNMODIFIED reference on 120 seeded random cases, live (build container only: /root/reference
-does not travel, so the test skips where it is absent -- the committed goldens of tests/golden/ are the portable pin).
+"""The oracle against the UNMODIFIED reference on 120 seeded random cases: live where /root/reference exists (build
+container; it does not travel, so those two tests skip elsewhere) and against the results committed from such a run.
 hippomm/utils/vector_ops.py:151-188 and hippomm/core/hippocampal_memory.py:944-967 run in a subprocess
 (tests/golden/live_reference.py); the oracle runs here on the same inputs, rebuilt from the same seeds."""
 import json
@@ -14,7 +14,7 @@ HERE = Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE / "golden"))
 import live_cases  # noqa: E402
 
-pytestmark = pytest.mark.skipif(not Path("/root/reference/hippomm").is_dir(), reason="/root/reference not present")
+needs_reference = pytest.mark.skipif(not Path("/root/reference/hippomm").is_dir(), reason="/root/reference not present")
 
 
 @pytest.fixture(scope="module")
@@ -24,6 +24,7 @@ def reference_results():
     return json.loads(r.stdout[r.stdout.index("{"):])
 
 
+@needs_reference
 @pytest.mark.filterwarnings("ignore:invalid value encountered")      # zero rows: 0/0 -> NaN, as in the reference
 def test_scan_oracle_equals_reference(reference_results):
     from oracle.vector_ops_oracle import top_k_cosine_similarity_oracle
@@ -36,6 +37,7 @@ def test_scan_oracle_equals_reference(reference_results):
         np.testing.assert_array_equal(np.asarray(sims, dtype=np.float64), want, err_msg=f"scan case {seed}: similarities")
 
 
+@needs_reference
 def test_select_oracle_equals_reference(reference_results):
     from oracle.consolidation_oracle import select_key_frames_oracle
     dropped = 0
@@ -45,3 +47,22 @@ def test_select_oracle_equals_reference(reference_results):
         assert [int(i) for i in kept] == ref, f"select case {seed}"
         dropped += f.shape[0] - len(ref)
     assert dropped > 1000                                   # the cases do exercise the rule
+
+
+@pytest.mark.filterwarnings("ignore:invalid value encountered")
+def test_oracles_equal_the_committed_reference_results():
+    """Portable form of the two tests above: tests/golden/live_golden.json holds what the unmodified reference returned for
+    the same 120 seeded cases (written by tests/golden/live_reference.py); the oracles must reproduce it exactly anywhere."""
+    from oracle.consolidation_oracle import select_key_frames_oracle
+    from oracle.vector_ops_oracle import top_k_cosine_similarity_oracle
+    gold = json.loads((HERE / "golden" / "live_golden.json").read_text())
+    assert len(gold["scan"]) == live_cases.N_SCAN and len(gold["select"]) == live_cases.N_SELECT
+    for seed, ref in enumerate(gold["scan"]):
+        q, store, k = live_cases.scan_case(seed)
+        idx, sims = top_k_cosine_similarity_oracle(q, store, k)
+        want = np.array([np.nan if s is None else s for s in ref["sims"]], dtype=np.float64)
+        assert [int(i) for i in idx] == ref["idx"], f"scan case {seed}"
+        np.testing.assert_array_equal(np.asarray(sims, dtype=np.float64), want, err_msg=f"scan case {seed}")
+    for seed, ref in enumerate(gold["select"]):
+        f, t, thr = live_cases.select_case(seed)
+        assert [int(i) for i in select_key_frames_oracle(f, t, thr)] == ref, f"select case {seed}"
