@@ -15,6 +15,7 @@
 //   - tile order is remapped so that the blocks that land on one XCD (blockIdx % 8) walk
 //     neighbouring tiles and share A / W panels in that XCD's L2.
 #include "hmm_common.h"
+#include "encoder_ops.h"
 #include "gemm_pp_mainloop.h"
 
 namespace hmm {
@@ -43,13 +44,35 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // software-pipelined one row-block ahead so that its load latency is not paid per element.
 template <int EPI, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float* __restrict__ bias,
-                                              void* __restrict__ Cout, int M, int N, int m_lane, int n_lane) {
+                                              void* __restrict__ Cout, int M, int N, int m_lane, int n_lane,
+                                              const GemmAux& aux) {
     float4 bv[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
         bv[ni] = bias ? *reinterpret_cast<const float4*>(bias + n_lane + ni * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
+    if constexpr (EPI == HMM_EPI_LN_BF16 || EPI == HMM_EPI_LN_GELU_BF16) {
+        float4 c1v[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) c1v[ni] = *reinterpret_cast<const float4*>(aux.c1 + n_lane + ni * 16);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m_lane + mi * 16;
+            if (m >= M) continue;
+            const float2 rs = aux.rs[(size_t)m * aux.rs_stride];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                f32x4 v = acc[mi][ni];
+                v[0] = ln_fold(v[0], rs, c1v[ni].x, bv[ni].x); v[1] = ln_fold(v[1], rs, c1v[ni].y, bv[ni].y);
+                v[2] = ln_fold(v[2], rs, c1v[ni].z, bv[ni].z); v[3] = ln_fold(v[3], rs, c1v[ni].w, bv[ni].w);
+                if constexpr (EPI == HMM_EPI_LN_GELU_BF16) {
+                    v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+                }
+                bf16x4 o4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(Cout) + (size_t)m * N + n_lane + ni * 16) = o4;
+            }
+        }
+    } else if constexpr (EPI == HMM_EPI_BIAS_RESID_F32 || EPI == HMM_EPI_BIAS_RESID_XB) {
         float* C = static_cast<float*>(Cout);
         float4 xin[2][NI];
         auto load_row = [&](int mi, float4 (&dst)[NI]) {
@@ -72,8 +95,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float*
                     const f32x4 v = acc[mi][ni];
                     // (accumulator + bias) + residual: the order of the ping-pong kernel's epilogue, so that a row gets the
                     // same bits from every tile geometry
-                    *reinterpret_cast<float4*>(C + (size_t)m * N + n_lane + ni * 16) =
-                        make_float4((v[0] + bv[ni].x) + x.x, (v[1] + bv[ni].y) + x.y, (v[2] + bv[ni].z) + x.z, (v[3] + bv[ni].w) + x.w);
+                    const float4 o = make_float4((v[0] + bv[ni].x) + x.x, (v[1] + bv[ni].y) + x.y, (v[2] + bv[ni].z) + x.z,
+                                                 (v[3] + bv[ni].w) + x.w);
+                    *reinterpret_cast<float4*>(C + (size_t)m * N + n_lane + ni * 16) = o;
+                    if constexpr (EPI == HMM_EPI_BIAS_RESID_XB) {
+                        bf16x4 o4 = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
+                        *reinterpret_cast<bf16x4*>(aux.xb + (size_t)m * N + n_lane + ni * 16) = o4;
+                    }
                 }
             }
         }
@@ -104,7 +132,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float*
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    void* __restrict__ Cout, int M, int N, int K, int tiles_n) {
+    void* __restrict__ Cout, int M, int N, int K, int tiles_n, GemmAux aux) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
@@ -197,7 +225,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
     }
 
     // epilogue: lane holds C[m][n .. n+3]
-    gemm_epilogue<EPI, MI, NI>(acc, bias, Cout, M, N, m0 + wm * TM + (lane & 15), n0 + wn * TN + 4 * (lane >> 4));
+    gemm_epilogue<EPI, MI, NI>(acc, bias, Cout, M, N, m0 + wm * TM + (lane & 15), n0 + wn * TN + 4 * (lane >> 4), aux);
 }
 
 
@@ -214,27 +242,45 @@ constexpr int kEpiSlab = 18432;                      // per-wave LDS slab: 128 r
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const float* __restrict__ bias,
                                                   void* __restrict__ Cout, int M, int N, int m_wave, int n_wave,
-                                                  char* slab, int lane) {
+                                                  char* slab, int lane, const GemmAux& aux) {
     const int fr = lane & 15, fq = lane >> 4;
     float4 bv[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
         bv[ni] = bias ? *reinterpret_cast<const float4*>(bias + n_wave + ni * 16 + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    if constexpr (EPI == HMM_EPI_BIAS_BF16 || EPI == HMM_EPI_BIAS_GELU_BF16) {
+    constexpr bool LNF = EPI == HMM_EPI_LN_BF16 || EPI == HMM_EPI_LN_GELU_BF16;
+    if constexpr (EPI == HMM_EPI_BIAS_BF16 || EPI == HMM_EPI_BIAS_GELU_BF16 || LNF) {
         constexpr int RS = 144;
+        float4 c1v[4];
+        if constexpr (LNF) {
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
+            for (int ni = 0; ni < 4; ++ni) c1v[ni] = *reinterpret_cast<const float4*>(aux.c1 + n_wave + ni * 16 + 4 * fq);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            float2 rs = make_float2(0.f, 0.f);
+            if constexpr (LNF) {
+                int m = m_wave + mi * 16 + fr;
+                m = m < M ? m : M - 1;
+                rs = aux.rs[(size_t)m * aux.rs_stride];
+            }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 f32x4 v = acc[mi][ni];
-                v[0] += bv[ni].x; v[1] += bv[ni].y; v[2] += bv[ni].z; v[3] += bv[ni].w;
-                if constexpr (EPI == HMM_EPI_BIAS_GELU_BF16) {
+                if constexpr (LNF) {
+                    v[0] = ln_fold(v[0], rs, c1v[ni].x, bv[ni].x); v[1] = ln_fold(v[1], rs, c1v[ni].y, bv[ni].y);
+                    v[2] = ln_fold(v[2], rs, c1v[ni].z, bv[ni].z); v[3] = ln_fold(v[3], rs, c1v[ni].w, bv[ni].w);
+                } else {
+                    v[0] += bv[ni].x; v[1] += bv[ni].y; v[2] += bv[ni].z; v[3] += bv[ni].w;
+                }
+                if constexpr (EPI == HMM_EPI_BIAS_GELU_BF16 || EPI == HMM_EPI_LN_GELU_BF16) {
                     v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
                 }
                 bf16x4 o4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                 *reinterpret_cast<bf16x4*>(slab + (mi * 16 + fr) * RS + (ni * 16 + 4 * fq) * 2) = o4;
             }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         bf16_t* C = static_cast<bf16_t*>(Cout);
@@ -251,6 +297,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
         }
     } else {
         constexpr int RS = 272;
+        constexpr bool RESID = EPI == HMM_EPI_BIAS_RESID_F32 || EPI == HMM_EPI_BIAS_RESID_XB;
         float* C = static_cast<float*>(Cout);
         const int rsub = lane >> 4, chunk = lane & 15;
         // Software-pipelined over the two 64-row halves: the residual rows of half 1 are requested as soon as half 0's
@@ -281,27 +328,49 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
             __builtin_amdgcn_wave_barrier();
         };
         auto drain = [&](int half) {                             // slab rows (+ residual) -> C, 256 B per 16 lanes
+            uint2 xb_even = make_uint2(0u, 0u);                   // RESID_XB: bf16 of the even iteration's row, kept for pairing
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int row = it * 4 + rsub;
                 float4 v = *reinterpret_cast<const float4*>(slab + row * RS + chunk * 16);
                 const int m = m_wave + half * 64 + row;
-                if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
+                if constexpr (RESID) {
                     v.x += xin[half][it].x; v.y += xin[half][it].y; v.z += xin[half][it].z; v.w += xin[half][it].w;
                 }
                 if (m < M) {
-                    if constexpr (EPI == HMM_EPI_BIAS_RESID_F32)
+                    if constexpr (RESID)
                         __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(C + (size_t)m * N + n_wave + chunk * 4));
                     else
                         *reinterpret_cast<float4*>(C + (size_t)m * N + n_wave + chunk * 4) = v;
+                }
+                if constexpr (EPI == HMM_EPI_BIAS_RESID_XB) {
+                    // The bf16 image of the new residual rows, 16 B per lane: a lane holds 4 columns (8 B) of row `it` and of
+                    // row `it + 1`; neighbours (chunk ^ 1) swap halves so that the even lane stores 8 columns of the first
+                    // row and the odd lane 8 columns of the second -- whole 128-B lines, half the store instructions (8-B
+                    // stores made the out-proj epilogue 51 us longer, 16-B ones ... see DESIGN.md 4.5).
+                    bf16x4 o4 = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+                    const uint2 cur = __builtin_bit_cast(uint2, o4);
+                    if ((it & 1) == 0) {
+                        xb_even = cur;
+                    } else {
+                        const bool odd = chunk & 1;
+                        const uint2 send = odd ? xb_even : cur;   // what the neighbour stores: its row's other half
+                        uint2 recv;
+                        recv.x = (unsigned)__shfl_xor((int)send.x, 1, 64);
+                        recv.y = (unsigned)__shfl_xor((int)send.y, 1, 64);
+                        const int m_st = odd ? m : m - 4;         // odd lanes store row `it`, even lanes row `it - 1`
+                        const uint4 q = odd ? make_uint4(recv.x, recv.y, cur.x, cur.y) : make_uint4(xb_even.x, xb_even.y, recv.x, recv.y);
+                        if (m_st < M)
+                            *reinterpret_cast<uint4*>(aux.xb + (size_t)m_st * N + n_wave + (chunk & ~1) * 4) = q;
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is re-used: reads must be done
             __builtin_amdgcn_wave_barrier();
         };
-        if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) load_resid(0);
+        if constexpr (RESID) load_resid(0);
         park(0);
-        if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) load_resid(1);
+        if constexpr (RESID) load_resid(1);
         drain(0);
         park(1);
         drain(1);
@@ -332,7 +401,7 @@ extern "C" void hmm_probe_set_gemm_stamps(unsigned long long* p) { g_gemm_stamps
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    void* __restrict__ Cout, int M, int N, int K, int tiles_n HMM_PROBE_ARG) {
+    void* __restrict__ Cout, int M, int N, int K, int tiles_n, GemmAux aux HMM_PROBE_ARG) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -394,7 +463,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 #ifdef HMM_PROBE
     if (stamps && threadIdx.x == 0) stamps[(size_t)bid * 8 + 7] = __builtin_amdgcn_s_memtime();     // shader-clock ticks
 #endif
-    gemm_epilogue_lds<EPI>(acc, bias, Cout, M, N, m0 + wm * 128, n0 + wn * 64, smem + wave * kEpiSlab, lane);
+    gemm_epilogue_lds<EPI>(acc, bias, Cout, M, N, m0 + wm * 128, n0 + wn * 64, smem + wave * kEpiSlab, lane, aux);
 #ifdef HMM_PROBE
     if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     HMM_STAMP(3)
@@ -402,64 +471,70 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 }
 
 template <int EPI>
-static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, hipStream_t st) {
+static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                          const GemmAux& aux, hipStream_t st) {
     constexpr int LDS = 8 * kEpiSlab > 2 * 4 * 16384 ? 8 * kEpiSlab : 2 * 4 * 16384;
     const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
     auto kern = gemm_bf16_pp_kernel<EPI>;
     HMM_ENSURE_DYN_LDS(kern, LDS);
-    kern<<<tiles_m * tiles_n, 512, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n HMM_PROBE_VAL);
+    kern<<<tiles_m * tiles_n, 512, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n, aux HMM_PROBE_VAL);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_gemm_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                           int epi, hipStream_t st);
-
-static int launch_gemm_pp_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                              int epi, hipStream_t st) {
-    if ((size_t)M * K >= (1ull << 31) || (size_t)N * K >= (1ull << 31))       // 32-bit staging offsets
-        return launch_gemm_epi<256, 256, 2, 4>(A, W, bias, C, M, N, K, epi, st);
-    switch (epi) {
-        case HMM_EPI_BIAS_BF16:      return launch_gemm_pp<HMM_EPI_BIAS_BF16>(A, W, bias, C, M, N, K, st);
-        case HMM_EPI_BIAS_GELU_BF16: return launch_gemm_pp<HMM_EPI_BIAS_GELU_BF16>(A, W, bias, C, M, N, K, st);
-        case HMM_EPI_BIAS_RESID_F32: return launch_gemm_pp<HMM_EPI_BIAS_RESID_F32>(A, W, bias, C, M, N, K, st);
-        case HMM_EPI_F32:            return launch_gemm_pp<HMM_EPI_F32>(A, W, bias, C, M, N, K, st);
-    }
-    set_error("gemm: unknown epilogue %d", epi);
-    return HMM_E_INVALID;
-}
-
 template <int BM, int BN, int WM, int WN, int EPI>
-static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, hipStream_t st) {
+static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                       const GemmAux& aux, hipStream_t st) {
     constexpr int LDS = 2 * (BM + BN) * 128;
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI>;
     HMM_ENSURE_DYN_LDS(kern, LDS);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
-    kern<<<tiles_m * tiles_n, WM * WN * 64, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n);
+    kern<<<tiles_m * tiles_n, WM * WN * 64, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n, aux);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
 
+#define HMM_EPI_SWITCH(CALL)                                                              \
+    switch (epi) {                                                                        \
+        case HMM_EPI_BIAS_BF16:      return CALL(HMM_EPI_BIAS_BF16);                      \
+        case HMM_EPI_BIAS_GELU_BF16: return CALL(HMM_EPI_BIAS_GELU_BF16);                 \
+        case HMM_EPI_BIAS_RESID_F32: return CALL(HMM_EPI_BIAS_RESID_F32);                 \
+        case HMM_EPI_F32:            return CALL(HMM_EPI_F32);                            \
+        case HMM_EPI_BIAS_RESID_XB:  return CALL(HMM_EPI_BIAS_RESID_XB);                  \
+        case HMM_EPI_LN_BF16:        return CALL(HMM_EPI_LN_BF16);                        \
+        case HMM_EPI_LN_GELU_BF16:   return CALL(HMM_EPI_LN_GELU_BF16);                   \
+    }                                                                                     \
+    set_error("gemm: unknown epilogue %d", epi);                                          \
+    return HMM_E_INVALID;
+
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                           int epi, hipStream_t st) {
-    switch (epi) {
-        case HMM_EPI_BIAS_BF16:      return launch_gemm<BM, BN, WM, WN, HMM_EPI_BIAS_BF16>(A, W, bias, C, M, N, K, st);
-        case HMM_EPI_BIAS_GELU_BF16: return launch_gemm<BM, BN, WM, WN, HMM_EPI_BIAS_GELU_BF16>(A, W, bias, C, M, N, K, st);
-        case HMM_EPI_BIAS_RESID_F32: return launch_gemm<BM, BN, WM, WN, HMM_EPI_BIAS_RESID_F32>(A, W, bias, C, M, N, K, st);
-        case HMM_EPI_F32:            return launch_gemm<BM, BN, WM, WN, HMM_EPI_F32>(A, W, bias, C, M, N, K, st);
-    }
-    set_error("gemm: unknown epilogue %d", epi);
-    return HMM_E_INVALID;
+                           int epi, const GemmAux& aux, hipStream_t st) {
+#define HMM_CALL(E) launch_gemm<BM, BN, WM, WN, E>(A, W, bias, C, M, N, K, aux, st)
+    HMM_EPI_SWITCH(HMM_CALL)
+#undef HMM_CALL
 }
 
+static int launch_gemm_pp_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                              int epi, const GemmAux& aux, hipStream_t st) {
+    if ((size_t)M * K >= (1ull << 31) || (size_t)N * K >= (1ull << 31))       // 32-bit staging offsets
+        return launch_gemm_epi<256, 256, 2, 4>(A, W, bias, C, M, N, K, epi, aux, st);
+#define HMM_CALL(E) launch_gemm_pp<E>(A, W, bias, C, M, N, K, aux, st)
+    HMM_EPI_SWITCH(HMM_CALL)
+#undef HMM_CALL
+}
+#undef HMM_EPI_SWITCH
+
 int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int epi,
-              int tile, hipStream_t st) {
+              int tile, hipStream_t st, const GemmAux* aux_in) {
+    const GemmAux aux = aux_in ? *aux_in : GemmAux{};
     HMM_REQUIRE(A && W && C, HMM_E_INVALID, "gemm: null pointer");
     HMM_REQUIRE(M >= 1 && N >= 128 && K >= 64 && K % 64 == 0 && N % 128 == 0, HMM_E_INVALID,
                 "gemm: unsupported shape M=%d N=%d K=%d (need K%%64==0, N%%128==0)", M, N, K);
     HMM_REQUIRE(epi == HMM_EPI_F32 || bias != nullptr, HMM_E_INVALID, "gemm: epilogue %d needs a bias", epi);
+    HMM_REQUIRE(epi != HMM_EPI_BIAS_RESID_XB || aux.xb != nullptr, HMM_E_INVALID, "gemm: epilogue %d needs aux.xb", epi);
+    HMM_REQUIRE((epi != HMM_EPI_LN_BF16 && epi != HMM_EPI_LN_GELU_BF16) || (aux.rs != nullptr && aux.c1 != nullptr && aux.rs_stride >= 1),
+                HMM_E_INVALID, "gemm: epilogue %d needs aux.rs and aux.c1", epi);
     if (tile < 0) tile = HMM_GEMM_TILE_PP_PEELED;
     const bool pp_ok = N % 256 == 0 && K % 128 == 0;
     if ((tile == HMM_GEMM_TILE_PP_PEELED || tile == HMM_GEMM_TILE_256x256_PP) && !pp_ok) tile = HMM_GEMM_TILE_256x256;
@@ -472,24 +547,29 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
         const long tiles = (long)tiles_m * tiles_n;
         // few 256x256 tiles (cls-only last block, head): 128x128 tiles put 4x more CUs to work
-        if (tiles < 128) return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
+        if (tiles < 128) return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
         int peel = 0;
         if (tiles > 256 && tiles % 256 != 0 && tiles % 256 <= 64)
             for (int p = 1; p <= 2 && !peel; ++p)
                 if (((long)(tiles_m - p) * tiles_n) % 256 == 0) peel = p;
-        if (!peel) return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, st);
+        if (!peel) return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, aux, st);
         const int m_main = (tiles_m - peel) * 256;
-        int rc = launch_gemm_pp_epi(A, W, bias, C, m_main, N, K, epi, st);
+        int rc = launch_gemm_pp_epi(A, W, bias, C, m_main, N, K, epi, aux, st);
         if (rc != HMM_OK) return rc;
-        const size_t esz = (epi == HMM_EPI_BIAS_BF16 || epi == HMM_EPI_BIAS_GELU_BF16) ? 2 : 4;
+        const bool c_bf16 = epi == HMM_EPI_BIAS_BF16 || epi == HMM_EPI_BIAS_GELU_BF16 || epi == HMM_EPI_LN_BF16 ||
+                            epi == HMM_EPI_LN_GELU_BF16;
+        GemmAux tail = aux;                                      // the per-row operands move with the rows
+        if (tail.xb) tail.xb += (size_t)m_main * N;
+        if (tail.rs) tail.rs += (size_t)m_main * aux.rs_stride;
         return launch_gemm_epi<128, 128, 2, 2>(A + (size_t)m_main * K, W, bias,
-                                               static_cast<char*>(C) + (size_t)m_main * N * esz, M - m_main, N, K, epi, st);
+                                               static_cast<char*>(C) + (size_t)m_main * N * (c_bf16 ? 2 : 4), M - m_main, N, K,
+                                               epi, tail, st);
     }
     switch (tile) {
-        case HMM_GEMM_TILE_256x256_PP: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, st);
-        case HMM_GEMM_TILE_128x128:    return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
-        case HMM_GEMM_TILE_256x128:    return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
-        case HMM_GEMM_TILE_256x256:    return launch_gemm_epi<256, 256, 2, 4>(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_256x256_PP: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, aux, st);
+        case HMM_GEMM_TILE_128x128:    return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
+        case HMM_GEMM_TILE_256x128:    return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
+        case HMM_GEMM_TILE_256x256:    return launch_gemm_epi<256, 256, 2, 4>(A, W, bias, C, M, N, K, epi, aux, st);
     }
     set_error("gemm: unknown tile geometry %d", tile);
     return HMM_E_INVALID;
@@ -509,4 +589,21 @@ extern "C" int hmm_op_gemm_bf16_tile(const uint16_t* a_dev, const uint16_t* w_de
                                      void* c_dev, int M, int N, int K, int epilogue, int tile, hmm_stream_t stream) {
     return gemm_bf16(reinterpret_cast<const bf16_t*>(a_dev), reinterpret_cast<const bf16_t*>(w_dev), bias_dev, c_dev,
                      M, N, K, epilogue, tile, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hmm_op_gemm_bf16_ln(const uint16_t* a_dev, const uint16_t* wf_dev, const float* c2_dev, uint16_t* c_dev, int M,
+                                   int N, int K, int gelu, const float* rs_dev, int rs_stride, const float* c1_dev, int tile,
+                                   hmm_stream_t stream) {
+    GemmAux aux;
+    aux.rs = reinterpret_cast<const float2*>(rs_dev); aux.rs_stride = rs_stride; aux.c1 = c1_dev;
+    return gemm_bf16(reinterpret_cast<const bf16_t*>(a_dev), reinterpret_cast<const bf16_t*>(wf_dev), c2_dev, c_dev, M, N, K,
+                     gelu ? HMM_EPI_LN_GELU_BF16 : HMM_EPI_LN_BF16, tile, static_cast<hipStream_t>(stream), &aux);
+}
+
+extern "C" int hmm_op_gemm_bf16_resid_xb(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev, float* c_dev,
+                                         uint16_t* xb_dev, int M, int N, int K, int tile, hmm_stream_t stream) {
+    GemmAux aux;
+    aux.xb = reinterpret_cast<bf16_t*>(xb_dev);
+    return gemm_bf16(reinterpret_cast<const bf16_t*>(a_dev), reinterpret_cast<const bf16_t*>(w_dev), bias_dev, c_dev, M, N, K,
+                     HMM_EPI_BIAS_RESID_XB, tile, static_cast<hipStream_t>(stream), &aux);
 }

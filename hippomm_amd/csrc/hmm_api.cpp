@@ -12,5 +12,5 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace hmm
 
-extern "C" int hmm_abi_version(void) { return 2; }
+extern "C" int hmm_abi_version(void) { return 3; }
 extern "C" const char* hmm_last_error(void) { return hmm::g_err; }

@@ -34,10 +34,15 @@ constexpr int kFXOff = kFQOff + ((kFT * kFQRow + 15) / 16) * 16;       // cooper
 constexpr int kFLds = kFXOff + FusedCfg::X_BYTES;                      // 154,176 B (> the 131,072 B of GEMM staging)
 static_assert(kFLds >= 2 * kPPTile && kFLds <= 160 * 1024, "LDS plan of the fused kernel");
 
+// LNF (folded LayerNorm, encoder.hip): `a` is the bf16 image of the residual stream, `w` = bf16(gamma (.) in_proj_weight),
+// `bias` = c2 and the projection value is fma(rs.x, acc, fma(-rs.y, c1, c2)) with rs[row] = (rstd, rstd * mean) -- the same
+// expression as gemm_bf16's HMM_EPI_LN_BF16 epilogue, so the two routes stay bitwise equal.
+template <bool LNF>
 __global__ __launch_bounds__(512) void qkv_attention_kernel(
     const bf16_t* __restrict__ a /* [n_img*257][1280] LayerNorm output */, const bf16_t* __restrict__ w /* [3840][1280] */,
     const float* __restrict__ bias /* [3840] */, const bf16_t* __restrict__ qkv_cls /* [n_img][3840] */,
-    bf16_t* __restrict__ out /* [n_img*257][1280] */, int n_img, float scale_log2e) {
+    bf16_t* __restrict__ out /* [n_img*257][1280] */, int n_img, float scale_log2e,
+    const float2* __restrict__ rs /* [n_img*257] */, const float* __restrict__ c1 /* [3840] */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,20 +84,32 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
     char* q_lds = smem + kFQOff;
     {
         const int fr = lane & 15, fq = lane >> 4;
+        float2 rsv[8];
+        if constexpr (LNF) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) rsv[mi] = rs[(size_t)b * kFT + 1 + wm * 128 + mi * 16 + fr];
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int col = wn * 64 + ni * 16 + 4 * fq;                  // 4 consecutive tile columns, never across a part
             const int part = col / kFDH, d = col - part * kFDH;
             if (part < 3) {                                              // wave-uniform per (wn, ni) except the last group
                 const float4 bv = *reinterpret_cast<const float4*>(bias + part * kFD + h * kFDH + d);
+                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (LNF) cv = *reinterpret_cast<const float4*>(c1 + part * kFD + h * kFDH + d);
                 char* img = part == 0 ? q_lds : (part == 1 ? k_lds : v_lds);
-                const int rs = part == 0 ? kFQRow : (part == 1 ? FusedCfg::KROW : FusedCfg::VROW);
+                const int stride = part == 0 ? kFQRow : (part == 1 ? FusedCfg::KROW : FusedCfg::VROW);
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) {
                     const int tok = 1 + wm * 128 + mi * 16 + fr;
                     const f32x4 v = acc[mi][ni];
-                    const bf16x4 o4 = {(bf16_t)(v[0] + bv.x), (bf16_t)(v[1] + bv.y), (bf16_t)(v[2] + bv.z), (bf16_t)(v[3] + bv.w)};
-                    *reinterpret_cast<bf16x4*>(img + tok * rs + d * 2) = o4;
+                    bf16x4 o4;
+                    if constexpr (LNF)
+                        o4 = bf16x4{(bf16_t)ln_fold(v[0], rsv[mi], cv.x, bv.x), (bf16_t)ln_fold(v[1], rsv[mi], cv.y, bv.y),
+                                    (bf16_t)ln_fold(v[2], rsv[mi], cv.z, bv.z), (bf16_t)ln_fold(v[3], rsv[mi], cv.w, bv.w)};
+                    else
+                        o4 = bf16x4{(bf16_t)(v[0] + bv.x), (bf16_t)(v[1] + bv.y), (bf16_t)(v[2] + bv.z), (bf16_t)(v[3] + bv.w)};
+                    *reinterpret_cast<bf16x4*>(img + tok * stride + d * 2) = o4;
                 }
             }
         }
@@ -130,13 +147,19 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
 }
 
 int qkv_attention_bf16(const bf16_t* a, const bf16_t* w, const float* bias, const bf16_t* qkv_cls, bf16_t* out,
-                       int n_img, hipStream_t st) {
+                       int n_img, hipStream_t st, const float2* rs, const float* c1) {
     HMM_REQUIRE(a && w && bias && qkv_cls && out, HMM_E_INVALID, "qkv_attention: null pointer");
+    HMM_REQUIRE((rs == nullptr) == (c1 == nullptr), HMM_E_INVALID, "qkv_attention: row statistics and c1 go together");
     HMM_REQUIRE(n_img >= 1 && (int64_t)n_img * kFT * kFD < (1ll << 31), HMM_E_INVALID, "qkv_attention: n_img=%d out of range", n_img);
-    HMM_ENSURE_DYN_LDS(qkv_attention_kernel, kFLds);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)kFDH);
     const int grid = 8 * ((n_img + 7) / 8) * kFH;
-    qkv_attention_kernel<<<grid, 512, kFLds, st>>>(a, w, bias, qkv_cls, out, n_img, scale_log2e);
+    if (rs) {
+        HMM_ENSURE_DYN_LDS(qkv_attention_kernel<true>, kFLds);
+        qkv_attention_kernel<true><<<grid, 512, kFLds, st>>>(a, w, bias, qkv_cls, out, n_img, scale_log2e, rs, c1);
+    } else {
+        HMM_ENSURE_DYN_LDS(qkv_attention_kernel<false>, kFLds);
+        qkv_attention_kernel<false><<<grid, 512, kFLds, st>>>(a, w, bias, qkv_cls, out, n_img, scale_log2e, nullptr, nullptr);
+    }
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
@@ -150,4 +173,13 @@ extern "C" int hmm_op_qkv_attention_bf16(const uint16_t* a_dev, const uint16_t* 
     return qkv_attention_bf16(reinterpret_cast<const bf16_t*>(a_dev), reinterpret_cast<const bf16_t*>(w_dev), bias_dev,
                               reinterpret_cast<const bf16_t*>(qkv_cls_dev), reinterpret_cast<bf16_t*>(out_dev), n_img,
                               static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hmm_op_qkv_attention_ln_bf16(const uint16_t* xb_dev, const uint16_t* wf_dev, const float* c2_dev,
+                                            const uint16_t* qkv_cls_dev, uint16_t* out_dev, int n_img, const float* rs_dev,
+                                            const float* c1_dev, hmm_stream_t stream) {
+    HMM_REQUIRE(rs_dev && c1_dev, HMM_E_INVALID, "qkv_attention_ln: null statistics");
+    return qkv_attention_bf16(reinterpret_cast<const bf16_t*>(xb_dev), reinterpret_cast<const bf16_t*>(wf_dev), c2_dev,
+                              reinterpret_cast<const bf16_t*>(qkv_cls_dev), reinterpret_cast<bf16_t*>(out_dev), n_img,
+                              static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(rs_dev), c1_dev);
 }

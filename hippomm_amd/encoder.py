@@ -113,6 +113,11 @@ class HipTower:
         """Vision tower: in_proj + attention as one kernel (default) or as GEMM + attention kernel; same bits."""
         _lib.check(self._lib.hmm_encoder_set_fused_attention(self._h, int(bool(on))), "hmm_encoder_set_fused_attention")
 
+    def set_folded_layernorm(self, on: bool):
+        """Vision tower: LayerNorm folded into the neighbouring GEMMs (default) or run as its own kernel; results agree
+        within the bf16 noise, not bitwise (include/hippomm_hip.h)."""
+        _lib.check(self._lib.hmm_encoder_set_folded_layernorm(self._h, int(bool(on))), "hmm_encoder_set_folded_layernorm")
+
     def set_streams(self, n: int):
         """2 (default): half-batches on two streams from batch*clips >= 64 on; 1: a single chain."""
         _lib.check(self._lib.hmm_encoder_set_streams(self._h, int(n)), "hmm_encoder_set_streams")

@@ -163,6 +163,13 @@ int  hmm_encoder_set_streams(hmm_encoder* enc, int n_streams);
  * packed qkv matrix never goes through HBM; off = a QKV GEMM followed by the attention kernel.  Embeddings are bitwise
  * identical either way.  No effect on the audio / text towers (their head shapes keep the two-kernel path). */
 int  hmm_encoder_set_fused_attention(hmm_encoder* enc, int on);
+/* Vision tower, every block but the last: on (default once all parameters are loaded) = no LayerNorm pass over the residual
+ * stream.  The residual GEMMs also emit xb = bf16(x); a statistics kernel takes (rstd, rstd * mean) of the xb rows; in_proj
+ * and fc1 run on xb with weights bf16(gamma (.) W) and finish the normalisation in their epilogue:
+ *   LN(xb) W^T + b = rstd * (xb W'^T) - rstd * mean * rowsum(W') + (W beta + b).
+ * off = the LayerNorm kernel (fp32 statistics of x, result rounded to bf16) + plain GEMMs, as the audio / text towers run.
+ * Same function, different rounding points: results differ within the bf16 noise (parity tests hold for both). */
+int  hmm_encoder_set_folded_layernorm(hmm_encoder* enc, int on);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side vision preprocessing.  Replaces, for already decoded frames, the transform chain of
@@ -239,6 +246,23 @@ int hmm_op_attention_bf16(const uint16_t* qkv_dev, uint16_t* out_dev, int batch,
  * Bitwise equal to hmm_op_gemm_bf16(HMM_EPI_BIAS_BF16) + hmm_op_attention_bf16. */
 int hmm_op_qkv_attention_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
                               const uint16_t* qkv_cls_dev, uint16_t* out_dev, int n_img, hmm_stream_t stream);
+/* Folded-LayerNorm pieces (hmm_encoder_set_folded_layernorm), exported for the parity tests:
+ *   hmm_op_rowstat_bf16       rs[r] = (rstd, rstd * mean) of row r of xb [rows][dim] bf16 (dim = 768 / 1024 / 1280), eps inside
+ *                             the square root as nn.LayerNorm;
+ *   hmm_op_fold_ln_weights    wf = bf16(gamma (.) w0) [n][dim], c1[n] = sum_k wf[n][k], c2[n] = sum_k w0[n][k] beta[k] + bias[n];
+ *   hmm_op_gemm_bf16_ln       C_bf16 = [gelu](rs[m*rs_stride].x * (A wf^T) - rs[..].y * c1 + c2)   (gelu != 0: with GELU);
+ *   hmm_op_gemm_bf16_resid_xb C_f32 += A W^T + bias as HMM_EPI_BIAS_RESID_F32, and xb = bf16(C_f32);
+ *   hmm_op_qkv_attention_ln_bf16  hmm_op_qkv_attention_bf16 on xb / wf / c2 with the normalisation in the kernel. */
+int hmm_op_rowstat_bf16(const uint16_t* xb_dev, float* rs_dev, int rows, int dim, float eps, hmm_stream_t stream);
+int hmm_op_fold_ln_weights(const float* w0_dev, const float* gamma_dev, const float* beta_dev, const float* bias_dev,
+                           uint16_t* wf_dev, float* c1_dev, float* c2_dev, int n, int dim, hmm_stream_t stream);
+int hmm_op_gemm_bf16_ln(const uint16_t* a_dev, const uint16_t* wf_dev, const float* c2_dev, uint16_t* c_dev, int M, int N, int K,
+                        int gelu, const float* rs_dev, int rs_stride, const float* c1_dev, int tile, hmm_stream_t stream);
+int hmm_op_gemm_bf16_resid_xb(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev, float* c_dev,
+                              uint16_t* xb_dev, int M, int N, int K, int tile, hmm_stream_t stream);
+int hmm_op_qkv_attention_ln_bf16(const uint16_t* xb_dev, const uint16_t* wf_dev, const float* c2_dev,
+                                 const uint16_t* qkv_cls_dev, uint16_t* out_dev, int n_img, const float* rs_dev,
+                                 const float* c1_dev, hmm_stream_t stream);
 /* Causal variant (text tower): key j is visible to query i iff j <= i; no bias_kv. */
 int hmm_op_attention_causal_bf16(const uint16_t* qkv_dev, uint16_t* out_dev, int batch, int tokens,
                                  int heads, int head_dim, hmm_stream_t stream);
