@@ -36,6 +36,7 @@ from __future__ import annotations
 
 import argparse
 import glob
+import hashlib
 import json
 import os
 import subprocess
@@ -65,9 +66,29 @@ REHEARSAL = os.environ.get("HMM_BENCH_REHEARSAL") == "1"
 # ------------------------------------------------------------------------------------------------
 # launching
 # ------------------------------------------------------------------------------------------------
+def visible_gpu_count(topology: str = "/sys/class/kfd/kfd/topology/nodes") -> int:
+    """GPUs this process would see, counted WITHOUT opening the HIP runtime (the self-launching parent must never touch the
+    GPU): the KFD topology in sysfs lists one node per agent, GPUs are the nodes with SIMDs; ROCR_VISIBLE_DEVICES /
+    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow the set exactly as the runtime would apply them."""
+    n = 0
+    for path in glob.glob(os.path.join(topology, "*", "properties")):
+        try:
+            props = dict(line.split(None, 1) for line in open(path).read().splitlines() if " " in line)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is not None:
+            n = min(n, len([v for v in val.split(",") if v.strip() != ""]))
+    return n
+
+
 def launch_ranks(n: int, argv) -> int:
-    """Parent of a self-launched multi-GPU run.  Must not initialise the GPU: device_count() does not."""
-    visible = torch.cuda.device_count()
+    """Parent of a self-launched multi-GPU run.  Never initialises the GPU: the GPUs are counted from sysfs and the ranks are
+    fresh child processes."""
+    visible = visible_gpu_count()
     if visible < n and not REHEARSAL:
         print(f"bench.py: --gpus {n} but only {visible} GPU(s) visible", file=sys.stderr)
         return 3
@@ -144,6 +165,25 @@ def profile_summary(pattern: str, kernel: str):
         if doc.get("kernel") == kernel and "traffic_bytes_per_launch" in doc:
             return int(doc["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
     return None, None
+
+
+def committed_n1_value(workload: str):
+    """The 1-GPU value of the same workload that is on disk: the driver's newest BENCH_r*.json (cfg2, the default run) or a
+    committed profiles/*bench_line*.json of that workload -> {"value", "source"} or None."""
+    cands = sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")), reverse=True) + \
+        sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line*.json")), reverse=True)
+    for path in cands:
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        doc = doc.get("parsed", doc) if isinstance(doc, dict) else None
+        if not isinstance(doc, dict) or doc.get("n_gpus") != 1 or "value" not in doc:
+            continue
+        wl = str(doc.get("config", {}).get("workload", ""))
+        if ("cfg2" in wl) == (workload == "cfg2") and ("cfg5" in wl) == (workload == "cfg5"):
+            return {"value": float(doc["value"]), "source": os.path.relpath(path, ROOT)}
+    return None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -406,13 +446,34 @@ def sharded_scan_bench(rank, world, reduce_max):
     q = torch.randn(1024, generator=torch.Generator(device="cuda").manual_seed(43), device="cuda")
     out = {"metric": "cosine-scan GB/s over a row-sharded store (feature_search, 1024-d fp32 rows, top-32, 1 query)",
            "unit": "GB/s", "exchange": "all-gather of 32 packed keys + 1 row offset per rank, merge on every rank"}
+
+    def all_ranks_ok(ok: bool) -> bool:
+        """Every rank takes the same path: a rank that failed locally (allocation, a kernel error) tells the others BEFORE
+        anybody enters a collective, so nobody waits in an all-gather for a rank that has left."""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
     for tag, n_local in (("weak_1M_rows_per_gpu", SCAN_ROWS), ("strong_1M_rows_total", SCAN_ROWS // world)):
-        g = torch.Generator(device="cuda").manual_seed(1000 + rank)
-        rows = torch.empty(n_local, 1024, dtype=torch.float32, device="cuda")
-        for s in range(0, n_local, 125_000):
-            blk = torch.randn(min(125_000, n_local - s), 1024, generator=g, device="cuda")
-            rows[s:s + blk.shape[0]] = blk / blk.norm(dim=1, keepdim=True)
-        store = FeatureStore(rows)
+        rows = store = None
+        err = None
+        try:
+            g = torch.Generator(device="cuda").manual_seed(1000 + rank)
+            rows = torch.empty(n_local, 1024, dtype=torch.float32, device="cuda")
+            for s in range(0, n_local, 125_000):
+                blk = torch.randn(min(125_000, n_local - s), 1024, generator=g, device="cuda")
+                rows[s:s + blk.shape[0]] = blk / blk.norm(dim=1, keepdim=True)
+            store = FeatureStore(rows)
+            store.search_keys_device(q, SCAN_K)                # the local leg once, outside any collective
+            torch.cuda.synchronize()
+        except Exception as exc:                               # noqa: BLE001 - reported in the line, and fails the run
+            err = f"rank {rank}: {type(exc).__name__}: {exc}"
+        if not all_ranks_ok(err is None):
+            out[tag] = {"error": err or "another rank failed before the exchange"}
+            out["error"] = f"{tag}: {out[tag]['error']}"
+            del rows, store
+            torch.cuda.empty_cache()
+            continue
         offset = rank * n_local
         query = lambda: sharded_top_k(q, SCAN_K, n_local, offset, store.search_keys_device)
         idx, sims = query()
@@ -424,7 +485,10 @@ def sharded_scan_bench(rank, world, reduce_max):
         dist.all_gather(cand_i, (local.indices + offset).contiguous())
         best = torch.topk(torch.cat(cand_v), SCAN_K + 1)
         want = torch.cat(cand_i)[best.indices]
-        separated = (best.values[:-1] - best.values[1:])[:SCAN_K] > 2e-6
+        gap = best.values[:-1] - best.values[1:]                 # gap[i] = value i - value i+1, i = 0 .. SCAN_K-1
+        below = gap[:SCAN_K] > 2e-6
+        above = torch.cat([torch.ones(1, dtype=torch.bool, device=gap.device), gap[:SCAN_K - 1] > 2e-6])
+        separated = below & above                                # a rank is pinned only when BOTH neighbours are clear of it
         ok = bool(idx.numel() == SCAN_K and torch.equal(idx[separated], want[:SCAN_K][separated]))
         dist.barrier()
         ms = reduce_max(event_time_ms(query, 20, warmup=3))
@@ -434,7 +498,7 @@ def sharded_scan_bench(rank, world, reduce_max):
                     "indices_match_torch_where_separated": ok}
         del rows, store, local
         torch.cuda.empty_cache()
-    out["value"] = out["weak_1M_rows_per_gpu"]["GBps_all_gpus"]
+    out["value"] = out["weak_1M_rows_per_gpu"].get("GBps_all_gpus")
     return out
 
 
@@ -476,7 +540,7 @@ def main():
         torch.cuda.set_device(0)
     n_gpus = world
 
-    from hippomm_amd.consolidation import select_key_frames_device
+    from hippomm_amd.consolidation import select_key_frames_async
     from hippomm_amd.encoder import HipTower, synthetic_state_dict
     from hippomm_amd.sharding import all_gather_embeddings, shard_bounds
 
@@ -503,7 +567,8 @@ def main():
             tower.forward_into(x[s:s + FRAMES_PER_GPU], emb[s:s + FRAMES_PER_GPU])
         return emb
 
-    step = make_step(frames, counts, encode, all_gather_embeddings, select_key_frames_device)
+    # launch-only until the final sync of the timed region: the selection returns (kept buffer, count) on the device
+    step = make_step(frames, counts, encode, all_gather_embeddings, select_key_frames_async)
 
     def reduce_max(x):
         if world == 1:
@@ -512,17 +577,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    elapsed, (feats, kept) = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize,
-                                         (dist.barrier if world > 1 else (lambda: None)), reduce_max)
+    elapsed, (feats, (kept_buf, n_kept)) = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize,
+                                                       (dist.barrier if world > 1 else (lambda: None)), reduce_max)
+    kept = kept_buf[: int(n_kept.item())].clone()
+
+    proof = None
+    if world > 1:
+        # self-proving N: a sum of ones over the data-path backend, every rank's device, and the shard each one encoded
+        ones = torch.ones(1, dtype=torch.int32, device="cuda")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
+                "gcn_arch": getattr(props, "gcnArchName", None), "pci_bus_id": getattr(props, "pci_bus_id", None),
+                "frames": hi - lo}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        proof = {"backend": dist.get_backend(), "all_reduced_rank_count": int(ones.item()), "ranks": everyone}
 
     gather_ms = None
     sharded_scan = None
     if world > 1:                                              # the exchange step alone
         gather_ms = reduce_max(event_time_ms(lambda: all_gather_embeddings(emb, counts), 20, warmup=3))
         if not args.no_scan:
-            try:                                               # the same code on every rank: a failure is a failure on all of them
+            # rank-local failures are agreed on inside (all_ranks_ok) before any collective; what still raises here raises on
+            # every rank alike.  Either way the line carries scan.error and the run exits non-zero.
+            try:
                 sharded_scan = sharded_scan_bench(rank, world, reduce_max)
-            except Exception as exc:                           # the encoder line must survive a problem in the scan leg
+            except Exception as exc:                           # noqa: BLE001
                 sharded_scan = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
@@ -554,9 +635,22 @@ def main():
                               "frames_total": n_total, "frames_per_rank": counts, "sharding": f"time shards x{n_gpus}",
                               "kept_key_frames": int(kept.numel()),
                               "kept_equal_cpu_oracle_on_gathered_matrix": kept.cpu().tolist() == want.tolist(),
+                              # fingerprints: the same at every N (time shards + bitwise batch invariance of the tower)
+                              "gathered_embeddings_sha256": hashlib.sha256(feats.cpu().numpy().tobytes()).hexdigest(),
+                              "kept_indices_sha256": hashlib.sha256(kept.cpu().numpy().tobytes()).hexdigest(),
                               "all_gather_bytes_per_rank": max(counts) * 4096}
         if gather_ms is not None:
             line["config"]["all_gather_ms"] = round(gather_ms, 4)
+        if proof is not None:
+            line["rccl_ranks"] = proof["all_reduced_rank_count"] if proof["backend"] == "nccl" else None
+            line["collective_backend"] = ("nccl (RCCL)" if proof["backend"] == "nccl" else proof["backend"])
+            line["all_reduced_rank_count"] = proof["all_reduced_rank_count"]
+            line["ranks"] = proof["ranks"]
+            n1 = committed_n1_value(args.workload)
+            if n1 is not None and not REHEARSAL:
+                line["scaling_vs_n1"] = {"n1_value": n1["value"], "n1_source": n1["source"],
+                                         "ratio": round(value / n1["value"], 3),
+                                         "note": "this run's whole-job value / the committed 1-GPU value of the same workload"}
         line["step_tflops"] = round(enc_flops * args.steps / elapsed / 1e12, 1)
         line["step_mfma_frac"] = round(enc_flops * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4)
         line["flops_per_frame_nominal"] = tower.flops(1)
@@ -584,6 +678,12 @@ def main():
                 line["cpu_baseline"] = encoder_cpu_baseline(frames32)
         print(json.dumps(line), flush=True)
         bad = [k for k in ("parity_vs_oracle",) if k in line and not line[k].get("ok", True)]
+        if "scan" in line and "error" in line["scan"]:      # a missing second metric is a failed run, not a shorter line
+            bad.append("scan.error")
+        if args.workload == "cfg5" and not line["config"]["kept_equal_cpu_oracle_on_gathered_matrix"]:
+            bad.append("cfg5.kept_equal_cpu_oracle_on_gathered_matrix")
+        if proof is not None and proof["all_reduced_rank_count"] != world:
+            bad.append("all_reduced_rank_count")
         if "scan" in line and not line["scan"].get("parity_vs_oracle", {}).get("top32_indices_equal", True):
             bad.append("scan.parity_vs_oracle")
         for tag in ("weak_1M_rows_per_gpu", "strong_1M_rows_total"):

@@ -14,23 +14,41 @@ from . import _lib
 FEATURE_DIM = 1024
 
 
-def select_key_frames_device(features: torch.Tensor, similarity_threshold: float = 0.9) -> torch.Tensor:
-    """features: (n,1024) fp32 CUDA tensor -> kept indices int64 CUDA tensor (synchronises once
-    to read the count)."""
+_BUFFERS = {}        # (device, n) -> (kept int64[n], n_kept int32[1], workspace): a selection allocates nothing after its first call
+
+
+def select_key_frames_async(features: torch.Tensor, similarity_threshold: float = 0.9):
+    """features: (n,1024) fp32 CUDA tensor -> (kept int64[n], n_kept int32[1]) CUDA tensors, WITHOUT synchronising: the
+    kept indices are ``kept[:n_kept]`` once the stream has run.  Launch-only (no allocation after the first call for a
+    given n, no read-back); the two tensors are reused by the next call with the same n on the same device, so consume
+    or copy them before that."""
     lib = _lib.load()
     if features.dim() != 2 or features.shape[1] != FEATURE_DIM:
         raise ValueError(f"features must be (n,{FEATURE_DIM}), got {tuple(features.shape)}")
-    f = features.to(dtype=torch.float32).contiguous()
+    f = features if features.dtype == torch.float32 and features.is_contiguous() else features.to(dtype=torch.float32).contiguous()
     n = f.shape[0]
     dev = f.device
-    kept = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
-    n_kept = torch.zeros(1, dtype=torch.int32, device=dev)
-    need = lib.hmm_gram_select_workspace_bytes(n)
-    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    key = (dev.index, n)
+    buf = _BUFFERS.get(key)
+    if buf is None:
+        if len(_BUFFERS) >= 16:                             # a handful of sizes recur (frame buffer, per-video totals)
+            _BUFFERS.pop(next(iter(_BUFFERS)))
+        need = lib.hmm_gram_select_workspace_bytes(n)
+        buf = (torch.empty(max(n, 1), dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
+               torch.empty(max(need, 256), dtype=torch.uint8, device=dev))
+        _BUFFERS[key] = buf
+    kept, n_kept, ws = buf
     thr = float(np.float32(similarity_threshold))     # the reference compares in float32 (:960)
     _lib.check(lib.hmm_gram_select(f.data_ptr(), n, FEATURE_DIM, thr, kept.data_ptr(), n_kept.data_ptr(),
                                    ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "hmm_gram_select")
-    return kept[: int(n_kept.item())]
+    return kept, n_kept
+
+
+def select_key_frames_device(features: torch.Tensor, similarity_threshold: float = 0.9) -> torch.Tensor:
+    """features: (n,1024) fp32 CUDA tensor -> kept indices int64 CUDA tensor (synchronises once to read the count; the
+    result is the caller's own tensor)."""
+    kept, n_kept = select_key_frames_async(features, similarity_threshold)
+    return kept[: int(n_kept.item())].clone()
 
 
 def select_key_frames(features: Union[np.ndarray, torch.Tensor], times: Optional[np.ndarray] = None,

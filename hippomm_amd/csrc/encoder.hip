@@ -185,7 +185,7 @@ static void plan_params(hmm_encoder* e, std::vector<std::pair<void**, size_t>>& 
     e->arena_bytes = ab.cursor;
 }
 
-struct WsPlan { int n_img, R; size_t off_x, off_a, off_big, off_im2col, off_patch, off_hl, off_hv, off_xc, off_ac, off_qc, off_hc, off_sel, off_xb, off_rs, off_rsc, total; };
+struct WsPlan { int n_img, R; size_t off_x, off_a, off_big, off_im2col, off_patch, off_hl, off_hv, off_xc, off_ac, off_qc, off_hc, off_sel, off_xb, off_rs, off_part, total; };
 
 static WsPlan ws_plan(const hmm_encoder* e, int batch) {
     WsPlan p{};
@@ -211,11 +211,11 @@ static WsPlan ws_plan(const hmm_encoder* e, int batch) {
     p.off_hc = cur;  cur = align_up(cur + (size_t)p.n_img * e->mlp * 2, 256);
     p.off_sel = cur; cur = align_up(cur + (size_t)p.n_img * 4, 256);
     // folded LayerNorm (vision): the bf16 image of the residual stream and its row statistics
-    p.off_xb = p.off_rs = p.off_rsc = cur;
+    p.off_xb = p.off_rs = p.off_part = cur;
     if (e->tower == HMM_TOWER_VISION) {
-        p.off_xb = cur;  cur = align_up(cur + (size_t)p.R * D * 2, 256);
-        p.off_rs = cur;  cur = align_up(cur + (size_t)p.R * 8, 256);
-        p.off_rsc = cur; cur = align_up(cur + (size_t)p.n_img * 8, 256);
+        p.off_xb = cur;   cur = align_up(cur + (size_t)p.R * D * 2, 256);
+        p.off_rs = cur;   cur = align_up(cur + (size_t)p.R * 8, 256);
+        p.off_part = cur; cur = align_up(cur + (size_t)p.R * (D / 64) * 8, 256);
     }
     p.total = cur + 256;
     return p;
@@ -409,6 +409,7 @@ extern "C" double hmm_encoder_flops_executed(const hmm_encoder* e, int batch) {
 
 namespace hmm {
 HMM_TUNABLE(int, g_enc_cls_fork, 1)      // probe build: 0 = cls-row projection on the chain's own stream (A/B)
+HMM_TUNABLE(int, g_enc_fold_stats, 1)    // probe build: 0 = folded-LayerNorm row statistics by a pass over xb (A/B)
 
 struct Chain {                 // one (half-)batch travelling through the tower on one stream
     const void* input; float* out; char* ws; WsPlan p; hipStream_t st; int batch;
@@ -453,47 +454,55 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
     const bool fused = e->fused_attention && e->tower == HMM_TOWER_VISION && D == 1280 && e->heads == 16 && T == 257;
     if (e->fold_ln && e->tower == HMM_TOWER_VISION && i + 1 < e->depth) {
         // Folded LayerNorm (all blocks but the cls-only last one).  No LayerNorm pass over the residual stream: the
-        // residual epilogues (out-proj, fc2) also emit xb = bf16(x); a one-wave-per-row kernel takes (rstd, rstd * mean) of
-        // the xb rows; the consumers (in_proj, fc1) multiply xb by wf = bf16(gamma (.) W) and finish LayerNorm in their
-        // epilogue (encoder_ops.h: ln_fold).  Saves the 337-MB fp32 read of each LayerNorm: 505 MB per norm become
-        // 168 MB (xb store) + 168 MB (statistics pass).  LN(x) is applied to bf16(x) instead of being rounded after the
-        // normalisation: one activation rounding either way; rows whose mean is many standard deviations lose
-        // precision to the cancellation of the mean term.
+        // residual epilogues (out-proj, fc2) also emit xb = bf16(x) and, per row and 64-column chunk, the chunk statistics of
+        // what they stored; a row-per-thread kernel combines a row's 20 chunks into (rstd, rstd * mean) (10 MB instead of
+        // a 168-MB pass over xb); the consumers (in_proj, fc1) multiply xb by wf = bf16(gamma (.) W) and finish LayerNorm
+        // in their epilogue (encoder_ops.h: ln_fold).  Per norm 505 MB of LayerNorm traffic become the 168-MB xb store.
+        // LN(x) is applied to bf16(x) instead of being rounded after the normalisation: one activation rounding either
+        // way; rows whose mean is many standard deviations lose precision to the cancellation of the mean term
+        // (DESIGN.md 4.5).  Block 0 takes xb and its statistics from the assembled tokens with two small passes.
         bf16_t* xb = reinterpret_cast<bf16_t*>(c.ws + p.off_xb);
         float2* rs = reinterpret_cast<float2*>(c.ws + p.off_rs);
-        float2* rsc = reinterpret_cast<float2*>(c.ws + p.off_rsc);
-        GemmAux emit; emit.xb = xb;
+        float2* part = reinterpret_cast<float2*>(c.ws + p.off_part);
+        const bool in_epi = g_enc_fold_stats != 0;               // probe build: 0 = statistics by a pass over xb (A/B)
+        GemmAux emit; emit.xb = xb; emit.part = in_epi ? part : nullptr;
         GemmAux ln0; ln0.rs = rs; ln0.c1 = w.c1[0];
         GemmAux ln1; ln1.rs = rs; ln1.c1 = w.c1[1];
-        if (i == 0) HMM_TRY(launch_cast_bf16(x, xb, (int64_t)R * D, st));    // later: written by the previous block's fc2
+        auto stats = [&]() -> int {                              // rs of the xb rows the last residual GEMM wrote
+            return in_epi ? launch_rowstat_finalize(part, rs, R, D, 1e-6f, st) : launch_rowstat_bf16(xb, rs, R, D, 1e-6f, st);
+        };
+        if (i == 0) {                                            // later: written by the previous block's fc2
+            HMM_TRY(launch_cast_bf16(x, xb, (int64_t)R * D, st));
+            HMM_TRY(launch_rowstat_bf16(xb, rs, R, D, 1e-6f, st));
+        }
         if (fused) {
             // the cls rows (token 0 of every image) do not fit the fused kernel's 256-row tile: their q | k | v come from a
-            // small GEMM on a forked stream, beside the statistics pass of the full matrix
+            // small GEMM on a forked stream (their statistics are rows b * T of rs)
             hipStream_t cst = g_enc_cls_fork ? c.cls_st : st;
             if (g_enc_cls_fork) {
-                HMM_HIP_CHECK(hipEventRecord(c.ev_x, st));                    // xb of this block is final on `st`
+                HMM_HIP_CHECK(hipEventRecord(c.ev_x, st));                    // xb and rs of this block are final on `st`
                 HMM_HIP_CHECK(hipStreamWaitEvent(cst, c.ev_x, 0));
             }
             HMM_TRY(launch_gather_rows(xb, (size_t)T * D * 2, ac, n_img, D * 2, cst));
-            HMM_TRY(launch_rowstat_bf16(ac, rsc, n_img, D, 1e-6f, cst));      // same code, same values as rs[b * T]
-            GemmAux lc; lc.rs = rsc; lc.c1 = w.c1[0];
+            GemmAux lc; lc.rs = rs; lc.rs_stride = T; lc.c1 = w.c1[0];
             HMM_TRY(gemm_bf16(ac, w.wf[0], w.c2[0], hc, n_img, 3 * D, D, HMM_EPI_LN_BF16, -1, cst, &lc));
-            if (g_enc_cls_fork) HMM_HIP_CHECK(hipEventRecord(c.ev_cls, cst));
-            HMM_TRY(launch_rowstat_bf16(xb, rs, R, D, 1e-6f, st));
-            if (g_enc_cls_fork) HMM_HIP_CHECK(hipStreamWaitEvent(st, c.ev_cls, 0));
+            if (g_enc_cls_fork) {
+                HMM_HIP_CHECK(hipEventRecord(c.ev_cls, cst));
+                HMM_HIP_CHECK(hipStreamWaitEvent(st, c.ev_cls, 0));
+            }
             HMM_TRY(qkv_attention_bf16(xb, w.wf[0], w.c2[0], hc, big, n_img, st, rs, w.c1[0]));
             HMM_TRY(gemm_bf16(big, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_XB, -1, st, &emit));
         } else {
-            HMM_TRY(launch_rowstat_bf16(xb, rs, R, D, 1e-6f, st));
             HMM_TRY(gemm_bf16(xb, w.wf[0], w.c2[0], big, R, 3 * D, D, HMM_EPI_LN_BF16, -1, st, &ln0));
             HMM_TRY(attention_bf16(big, a, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st, false));
             HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_XB, -1, st, &emit));
         }
-        HMM_TRY(launch_rowstat_bf16(xb, rs, R, D, 1e-6f, st));
+        HMM_TRY(stats());
         HMM_TRY(gemm_bf16(xb, w.wf[1], w.c2[1], big, R, e->mlp, D, HMM_EPI_LN_GELU_BF16, -1, st, &ln1));
         const bool next_folded = i + 2 < e->depth;
         HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, next_folded ? HMM_EPI_BIAS_RESID_XB : HMM_EPI_BIAS_RESID_F32,
                           -1, st, &emit));
+        if (next_folded) HMM_TRY(stats());
         return HMM_OK;
     }
     if (!(i + 1 < e->depth && fused)) HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));

@@ -19,10 +19,23 @@ namespace hmm {
 // fused in_proj + attention kernel), so that the same numbers come out of every tile geometry.
 struct GemmAux {
     bf16_t* xb = nullptr;            // RESID_XB: [M][N] bf16
+    float2* part = nullptr;          // RESID_XB: [M][N / 64] chunk statistics of the xb rows (may be null), see chunk_stat_*
     const float2* rs = nullptr;      // LN*: row statistics, row m at rs[m * rs_stride]
     const float* c1 = nullptr;       // LN*: [N]
     int rs_stride = 1;
 };
+// Row statistics of xb without a pass over it: the RESID_XB epilogues also emit, per row and per 64-column chunk, (s, q) =
+// (sum, sum of squares about the chunk mean s/64) of the bf16 values they store, and launch_rowstat_finalize combines a row's
+// chunks (Chan's formula, chunk order) into (rstd, rstd * mean).  A chunk is reduced in ONE order whatever the tile geometry:
+// leaf j = columns 4j..4j+3 as (b0 + b1) + (b2 + b3) [squares: fma chain d3, d2, d1 onto d0 * d0], then an xor-butterfly over
+// j = 1, 2, 4, 8 -- lanes of a DPP row in the LDS-transposed epilogue (hmm_common.h row16_sum), lanes 16 / 32 apart and the
+// four 16-column blocks of a wave tile in the direct one -- so a row gets the same bits from every kernel.
+__device__ __forceinline__ float chunk_leaf_sum(float b0, float b1, float b2, float b3) { return (b0 + b1) + (b2 + b3); }
+__device__ __forceinline__ float chunk_leaf_sq(float b0, float b1, float b2, float b3, float mc) {
+    const float d0 = b0 - mc, d1 = b1 - mc, d2 = b2 - mc, d3 = b3 - mc;
+    return fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, d0 * d0)));
+}
+
 __device__ __forceinline__ float ln_fold(float acc, float2 rs, float c1, float c2) {
     return fmaf(rs.x, acc, fmaf(-rs.y, c1, c2));
 }
@@ -47,6 +60,7 @@ int launch_gather_selected_rows(const void* src, const int32_t* sel, int T, void
                                 hipStream_t st);
 int launch_cast_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t st);
 int launch_rowstat_bf16(const bf16_t* xb, float2* rs, int rows, int D, float eps, hipStream_t st);
+int launch_rowstat_finalize(const float2* part, float2* rs, int rows, int D, float eps, hipStream_t st);
 int launch_fold_ln_weights(const float* w0, const float* gamma, const float* beta, const float* bias, bf16_t* wf,
                            float* c1, float* c2, int N, int D, hipStream_t st);
 int launch_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);

@@ -277,6 +277,35 @@ __global__ __launch_bounds__(256) void rowstat_bf16_kernel(const bf16_t* __restr
     if (lane == 0) rs[row] = make_float2(rstd, rstd * mean);
 }
 
+// rs[r] = (rstd, rstd * mean) of row r from the per-chunk statistics the RESID_XB epilogues emitted (encoder_ops.h):
+// part[r][c] = (sum, sum of squares about the chunk mean) of columns 64 c .. 64 c + 63.  Chunks are combined in chunk order:
+// mean = (sum_c s_c) / D,  M2 = sum_c (q_c + 64 (s_c / 64 - mean)^2)  (Chan et al.), rstd = rsqrt(M2 / D + eps).
+template <int CHUNKS>
+__global__ __launch_bounds__(256) void rowstat_finalize_kernel(const float2* __restrict__ part, float2* __restrict__ rs, int rows,
+                                                               float eps) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    static_assert(CHUNKS % 2 == 0, "two chunks per 16-byte load");
+    const float4* p = reinterpret_cast<const float4*>(part + (size_t)row * CHUNKS);
+    float4 v[CHUNKS / 2];
+#pragma unroll
+    for (int c = 0; c < CHUNKS / 2; ++c) v[c] = p[c];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHUNKS / 2; ++c) { s += v[c].x; s += v[c].z; }
+    constexpr float inv_d = 1.0f / (64.0f * CHUNKS);
+    const float mean = s * inv_d;
+    float m2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHUNKS / 2; ++c) {
+        const float d0 = v[c].x * (1.0f / 64.0f) - mean, d1 = v[c].z * (1.0f / 64.0f) - mean;
+        m2 += fmaf(64.0f * d0, d0, v[c].y);
+        m2 += fmaf(64.0f * d1, d1, v[c].w);
+    }
+    const float rstd = rsqrtf(m2 * inv_d + eps);
+    rs[row] = make_float2(rstd, rstd * mean);
+}
+
 // One workgroup per output row n of a Linear that follows a LayerNorm:  wf[n][k] = bf16(gamma[k] * w0[n][k]),
 // c1[n] = sum_k wf[n][k] (of the ROUNDED values: it multiplies the same mean the product sees),
 // c2[n] = sum_k w0[n][k] * beta[k] + bias[n].  fp64 sums, fixed reduction order.
@@ -379,6 +408,15 @@ int launch_rowstat_bf16(const bf16_t* xb, float2* rs, int rows, int D, float eps
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
+int launch_rowstat_finalize(const float2* part, float2* rs, int rows, int D, float eps, hipStream_t st) {
+    HMM_REQUIRE(D == 1280 || D == 768 || D == 1024, HMM_E_INVALID, "rowstat_finalize: unsupported width %d", D);
+    const unsigned grid = (unsigned)((rows + 255) / 256);
+    if (D == 1280)      rowstat_finalize_kernel<20><<<grid, 256, 0, st>>>(part, rs, rows, eps);
+    else if (D == 1024) rowstat_finalize_kernel<16><<<grid, 256, 0, st>>>(part, rs, rows, eps);
+    else                rowstat_finalize_kernel<12><<<grid, 256, 0, st>>>(part, rs, rows, eps);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
 int launch_fold_ln_weights(const float* w0, const float* gamma, const float* beta, const float* bias, bf16_t* wf,
                            float* c1, float* c2, int N, int D, hipStream_t st) {
     fold_ln_weights_kernel<<<N, 256, 0, st>>>(w0, gamma, beta, bias, wf, c1, c2, D);
@@ -410,6 +448,12 @@ extern "C" int hmm_op_rowstat_bf16(const uint16_t* xb_dev, float* rs_dev, int ro
     HMM_REQUIRE(xb_dev && rs_dev && rows >= 1, HMM_E_INVALID, "rowstat: bad arguments");
     return hmm::launch_rowstat_bf16(reinterpret_cast<const hmm::bf16_t*>(xb_dev), reinterpret_cast<float2*>(rs_dev), rows, dim, eps,
                                     static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hmm_op_rowstat_finalize(const float* part_dev, float* rs_dev, int rows, int dim, float eps, hmm_stream_t stream) {
+    HMM_REQUIRE(part_dev && rs_dev && rows >= 1, HMM_E_INVALID, "rowstat_finalize: bad arguments");
+    return hmm::launch_rowstat_finalize(reinterpret_cast<const float2*>(part_dev), reinterpret_cast<float2*>(rs_dev), rows, dim, eps,
+                                        static_cast<hipStream_t>(stream));
 }
 
 extern "C" int hmm_op_fold_ln_weights(const float* w0_dev, const float* gamma_dev, const float* beta_dev, const float* bias_dev,

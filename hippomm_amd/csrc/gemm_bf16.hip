@@ -75,6 +75,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float*
     } else if constexpr (EPI == HMM_EPI_BIAS_RESID_F32 || EPI == HMM_EPI_BIAS_RESID_XB) {
         float* C = static_cast<float*>(Cout);
         float4 xin[2][NI];
+        float4 xbv[NI];
         auto load_row = [&](int mi, float4 (&dst)[NI]) {
             const int m = m_lane + mi * 16;
             if (m < M) {
@@ -101,7 +102,31 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float*
                     if constexpr (EPI == HMM_EPI_BIAS_RESID_XB) {
                         bf16x4 o4 = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
                         *reinterpret_cast<bf16x4*>(aux.xb + (size_t)m * N + n_lane + ni * 16) = o4;
+                        xbv[ni] = make_float4((float)o4[0], (float)o4[1], (float)o4[2], (float)o4[3]);
                     }
+                }
+                if constexpr (EPI == HMM_EPI_BIAS_RESID_XB) {
+                    // chunk statistics of the 64 columns of this wave tile (encoder_ops.h): leaf j = 4 ni + (lane >> 4); the lanes
+                    // 16 / 32 apart hold the same row (same m), so they are in this branch together
+                    static_assert(NI == 4, "chunk statistics: the wave tile must be 64 columns wide");
+                    float l[NI];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        l[ni] = chunk_leaf_sum(xbv[ni].x, xbv[ni].y, xbv[ni].z, xbv[ni].w);
+                        l[ni] += __shfl_xor(l[ni], 16, 64);
+                        l[ni] += __shfl_xor(l[ni], 32, 64);
+                    }
+                    const float s = (l[0] + l[1]) + (l[2] + l[3]);
+                    const float mc = s * (1.0f / 64.0f);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        l[ni] = chunk_leaf_sq(xbv[ni].x, xbv[ni].y, xbv[ni].z, xbv[ni].w, mc);
+                        l[ni] += __shfl_xor(l[ni], 16, 64);
+                        l[ni] += __shfl_xor(l[ni], 32, 64);
+                    }
+                    const float q = (l[0] + l[1]) + (l[2] + l[3]);
+                    if (aux.part != nullptr && (n_lane & 63) == 0)
+                        aux.part[(size_t)m * (N >> 6) + (n_lane >> 6)] = make_float2(s, q);
                 }
             }
         }
@@ -349,6 +374,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
                     // row and the odd lane 8 columns of the second -- whole 128-B lines, half the store instructions (8-B
                     // stores made the out-proj epilogue 51 us longer, 16-B ones ... see DESIGN.md 4.5).
                     bf16x4 o4 = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+                    {   // chunk statistics of this row's 64 columns (encoder_ops.h): leaf j = chunk, butterfly over the DPP row
+                        const float b0 = (float)o4[0], b1 = (float)o4[1], b2 = (float)o4[2], b3 = (float)o4[3];
+                        const float s = row16_sum(chunk_leaf_sum(b0, b1, b2, b3));
+                        const float q = row16_sum(chunk_leaf_sq(b0, b1, b2, b3, s * (1.0f / 64.0f)));
+                        if (aux.part != nullptr && chunk == 0 && m < M)
+                            aux.part[(size_t)m * (N >> 6) + (n_wave >> 6)] = make_float2(s, q);
+                    }
                     const uint2 cur = __builtin_bit_cast(uint2, o4);
                     if ((it & 1) == 0) {
                         xb_even = cur;
@@ -560,6 +592,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
                             epi == HMM_EPI_LN_GELU_BF16;
         GemmAux tail = aux;                                      // the per-row operands move with the rows
         if (tail.xb) tail.xb += (size_t)m_main * N;
+        if (tail.part) tail.part += (size_t)m_main * (N >> 6);
         if (tail.rs) tail.rs += (size_t)m_main * aux.rs_stride;
         return launch_gemm_epi<128, 128, 2, 2>(A + (size_t)m_main * K, W, bias,
                                                static_cast<char*>(C) + (size_t)m_main * N * (c_bf16 ? 2 : 4), M - m_main, N, K,
@@ -601,9 +634,10 @@ extern "C" int hmm_op_gemm_bf16_ln(const uint16_t* a_dev, const uint16_t* wf_dev
 }
 
 extern "C" int hmm_op_gemm_bf16_resid_xb(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev, float* c_dev,
-                                         uint16_t* xb_dev, int M, int N, int K, int tile, hmm_stream_t stream) {
+                                         uint16_t* xb_dev, float* part_dev, int M, int N, int K, int tile, hmm_stream_t stream) {
     GemmAux aux;
     aux.xb = reinterpret_cast<bf16_t*>(xb_dev);
+    aux.part = reinterpret_cast<float2*>(part_dev);
     return gemm_bf16(reinterpret_cast<const bf16_t*>(a_dev), reinterpret_cast<const bf16_t*>(w_dev), bias_dev, c_dev, M, N, K,
                      HMM_EPI_BIAS_RESID_XB, tile, static_cast<hipStream_t>(stream), &aux);
 }

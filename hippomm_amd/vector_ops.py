@@ -111,7 +111,9 @@ class FeatureStore:
             raise ValueError("no queries")
         lib = _lib.load()
         need = lib.hmm_cosine_topk_multi_workspace_bytes(n, nq, k)
-        ws = torch.empty(need, dtype=torch.uint8, device=self.rows.device)
+        if self._ws is None or self._ws.numel() < need:      # kept between calls, like the single-query workspace
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.rows.device)
+        ws = self._ws
         idx = torch.empty(nq, k, dtype=torch.int64, device=self.rows.device)
         sims = torch.empty(nq, k, dtype=torch.float32, device=self.rows.device)
         n_out = torch.empty(nq, dtype=torch.int32, device=self.rows.device)

@@ -251,7 +251,10 @@ int hmm_op_qkv_attention_bf16(const uint16_t* a_dev, const uint16_t* w_dev, cons
  *                             the square root as nn.LayerNorm;
  *   hmm_op_fold_ln_weights    wf = bf16(gamma (.) w0) [n][dim], c1[n] = sum_k wf[n][k], c2[n] = sum_k w0[n][k] beta[k] + bias[n];
  *   hmm_op_gemm_bf16_ln       C_bf16 = [gelu](rs[m*rs_stride].x * (A wf^T) - rs[..].y * c1 + c2)   (gelu != 0: with GELU);
- *   hmm_op_gemm_bf16_resid_xb C_f32 += A W^T + bias as HMM_EPI_BIAS_RESID_F32, and xb = bf16(C_f32);
+ *   hmm_op_gemm_bf16_resid_xb C_f32 += A W^T + bias as HMM_EPI_BIAS_RESID_F32, and xb = bf16(C_f32); part_dev (may be null):
+ *                             [M][N/64] pairs (sum, sum of squares about the chunk mean) of every 64-column chunk of xb's rows;
+ *   hmm_op_rowstat_finalize   rs[r] = (rstd, rstd * mean) of row r from its dim/64 chunk pairs (the statistics of
+ *                             hmm_op_rowstat_bf16 without a pass over xb; agrees with it to fp32 rounding);
  *   hmm_op_qkv_attention_ln_bf16  hmm_op_qkv_attention_bf16 on xb / wf / c2 with the normalisation in the kernel. */
 int hmm_op_rowstat_bf16(const uint16_t* xb_dev, float* rs_dev, int rows, int dim, float eps, hmm_stream_t stream);
 int hmm_op_fold_ln_weights(const float* w0_dev, const float* gamma_dev, const float* beta_dev, const float* bias_dev,
@@ -259,7 +262,8 @@ int hmm_op_fold_ln_weights(const float* w0_dev, const float* gamma_dev, const fl
 int hmm_op_gemm_bf16_ln(const uint16_t* a_dev, const uint16_t* wf_dev, const float* c2_dev, uint16_t* c_dev, int M, int N, int K,
                         int gelu, const float* rs_dev, int rs_stride, const float* c1_dev, int tile, hmm_stream_t stream);
 int hmm_op_gemm_bf16_resid_xb(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev, float* c_dev,
-                              uint16_t* xb_dev, int M, int N, int K, int tile, hmm_stream_t stream);
+                              uint16_t* xb_dev, float* part_dev, int M, int N, int K, int tile, hmm_stream_t stream);
+int hmm_op_rowstat_finalize(const float* part_dev, float* rs_dev, int rows, int dim, float eps, hmm_stream_t stream);
 int hmm_op_qkv_attention_ln_bf16(const uint16_t* xb_dev, const uint16_t* wf_dev, const float* c2_dev,
                                  const uint16_t* qkv_cls_dev, uint16_t* out_dev, int n_img, const float* rs_dev,
                                  const float* c1_dev, hmm_stream_t stream);

@@ -113,3 +113,20 @@ def test_bench_step_world2_gloo(n_frames):
         assert 1 < n_kept < n_frames, "the synthetic video must make the selection drop some frames and keep several"
         times.add(round(elapsed, 9))
     assert len(times) == 1, "every rank must report the max-over-ranks time"
+
+
+def test_gpu_count_comes_from_sysfs_not_from_hip(tmp_path, monkeypatch):
+    """The self-launching parent counts GPUs from the KFD topology (nodes with SIMDs), narrowed by *_VISIBLE_DEVICES."""
+    import bench
+    for i, simd in enumerate((0, 256, 256, 256)):                # node 0 is the CPU agent
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpu_count(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpu_count(str(tmp_path)) == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert bench.visible_gpu_count(str(tmp_path)) == 1
+    assert bench.visible_gpu_count(str(tmp_path / "absent")) == 0

@@ -107,9 +107,30 @@ def test_gemm_ln_epilogue_against_layernorm_then_linear(M, gelu):
     assert rel < 6e-3                                     # two bf16 operand roundings: ~2.5e-3 as for LN -> bf16 -> GEMM
 
 
+@pytest.mark.parametrize("dim", [768, 1024, 1280])
+def test_rowstat_finalize_on_rows_with_large_means(dim):
+    """Chunk statistics -> row statistics (Chan's combination) on rows whose mean is up to ~30 standard deviations: the
+    centred chunk sums keep the variance accurate where sum(x^2) - sum(x)^2 / n would not."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(dim + 1)
+    x = torch.randn(300, dim, generator=g) * torch.rand(300, 1, generator=g) * 3 + 30.0 * torch.randn(300, 1, generator=g)
+    x[7] = 0.0
+    x[8] = -3.5
+    xb = _bf16(x).double()
+    v = xb.view(300, dim // 64, 64)
+    part = torch.stack([v.sum(-1), ((v - v.mean(-1, keepdim=True)) ** 2).sum(-1)], dim=-1).float().cuda().contiguous()
+    rs = torch.empty(300, 2, device="cuda")
+    L.check(lib.hmm_op_rowstat_finalize(part.data_ptr(), rs.data_ptr(), 300, dim, 1e-6, L.stream_ptr()), "rowstat_finalize")
+    mean = xb.mean(1)
+    rstd = 1.0 / torch.sqrt(xb.var(1, unbiased=False) + 1e-6)
+    rs = rs.double().cpu()
+    assert torch.allclose(rs[:, 0], rstd, rtol=5e-6, atol=0)
+    assert torch.allclose(rs[:, 1], rstd * mean, rtol=5e-6, atol=1e-6 * float((rstd * mean).abs().max()))
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 def test_gemm_resid_xb_epilogue(tile):
-    """C += A W^T + bias exactly as HMM_EPI_BIAS_RESID_F32, plus xb = bf16(C)."""
+    """C += A W^T + bias exactly as HMM_EPI_BIAS_RESID_F32, plus xb = bf16(C) and the chunk statistics of xb."""
     L, lib = _lib()
     M, N, K = 771, 1280, 1280
     g = torch.Generator().manual_seed(9)
@@ -122,11 +143,31 @@ def test_gemm_resid_xb_epilogue(tile):
                                       L.stream_ptr()), "gemm resid")
     c = c0.clone()
     xb = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-    L.check(lib.hmm_op_gemm_bf16_resid_xb(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), xb.data_ptr(), M, N, K,
-                                          tile, L.stream_ptr()), "gemm resid xb")
+    part = torch.full((M + 1, N // 64, 2), float("nan"), device="cuda")
+    L.check(lib.hmm_op_gemm_bf16_resid_xb(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), xb.data_ptr(),
+                                          part.data_ptr(), M, N, K, tile, L.stream_ptr()), "gemm resid xb")
     assert torch.equal(c, plain)
     assert torch.equal(xb[:M], _bf16(c))
-    assert torch.isnan(xb[M:].float()).all()
+    assert torch.isnan(xb[M:].float()).all() and torch.isnan(part[M:]).all()
+    # chunk statistics: (sum, sum of squares about the chunk mean) of every 64 columns of the stored bf16 rows
+    v = xb[:M].double().view(M, N // 64, 64)
+    s, q = v.sum(-1), ((v - v.mean(-1, keepdim=True)) ** 2).sum(-1)
+    assert torch.allclose(part[:M, :, 0].double(), s, rtol=1e-6, atol=1e-5)
+    assert torch.allclose(part[:M, :, 1].double(), q, rtol=1e-5, atol=1e-6)
+    # ... combined per row they are the statistics of the pass over xb, and without the buffer nothing else changes
+    rs = torch.empty(M, 2, device="cuda")
+    L.check(lib.hmm_op_rowstat_finalize(part.data_ptr(), rs.data_ptr(), M, N, 1e-6, L.stream_ptr()), "rowstat_finalize")
+    ref_rs = _rowstat(L, lib, xb[:M].contiguous())
+    assert torch.allclose(rs, ref_rs, rtol=3e-6, atol=1e-6)
+    c2_, xb2 = c0.clone(), torch.empty_like(xb)
+    L.check(lib.hmm_op_gemm_bf16_resid_xb(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c2_.data_ptr(), xb2.data_ptr(), None,
+                                          M, N, K, tile, L.stream_ptr()), "gemm resid xb, no statistics")
+    assert torch.equal(c2_, c) and torch.equal(xb2[:M], xb[:M])
+    if tile:                                              # every tile geometry reduces a chunk in the same order: same bits
+        p0, x0, c3 = torch.empty_like(part), torch.empty_like(xb), c0.clone()
+        L.check(lib.hmm_op_gemm_bf16_resid_xb(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c3.data_ptr(), x0.data_ptr(),
+                                              p0.data_ptr(), M, N, K, 0, L.stream_ptr()), "gemm resid xb 128")
+        assert torch.equal(p0[:M], part[:M])
     if tile:                                              # and the same bits as the 128x128 tiles
         ref = c0.clone()
         L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), ref.data_ptr(), M, N, K, 2, 0,

@@ -12,6 +12,7 @@ a = torch.empty(R, D, dtype=torch.bfloat16, device="cuda")
 big = torch.empty(R, MLP, dtype=torch.bfloat16, device="cuda")
 g1, b1 = torch.ones(D, device="cuda"), torch.zeros(D, device="cuda")
 rs = torch.empty(R, 2, device="cuda")
+part = torch.empty(R, D // 64, 2, device="cuda")
 wo = (torch.randn(D, D, device="cuda") * 0.02).to(torch.bfloat16); bo = torch.zeros(D, device="cuda")
 w1 = (torch.randn(MLP, D, device="cuda") * 0.02).to(torch.bfloat16); bb1 = torch.zeros(MLP, device="cuda"); c1 = torch.randn(MLP, device="cuda")
 w2 = (torch.randn(D, MLP, device="cuda") * 0.02).to(torch.bfloat16); bb2 = torch.zeros(D, device="cuda")
@@ -21,10 +22,11 @@ L.check(lib.hmm_op_rowstat_bf16(xb.data_ptr(), rs.data_ptr(), R, D, 1e-6, S()), 
 tests = {
  "layernorm (replaced)": lambda: lib.hmm_op_layernorm_bf16(x.data_ptr(), g1.data_ptr(), b1.data_ptr(), a.data_ptr(), R, D, 1e-6, S()),
  "rowstat": lambda: lib.hmm_op_rowstat_bf16(xb.data_ptr(), rs.data_ptr(), R, D, 1e-6, S()),
+ "rowstat finalize": lambda: lib.hmm_op_rowstat_finalize(part.data_ptr(), rs.data_ptr(), R, D, 1e-6, S()),
  "out-proj resid": lambda: lib.hmm_op_gemm_bf16(a.data_ptr(), wo.data_ptr(), bo.data_ptr(), x.data_ptr(), R, D, D, 2, S()),
- "out-proj resid+xb": lambda: lib.hmm_op_gemm_bf16_resid_xb(a.data_ptr(), wo.data_ptr(), bo.data_ptr(), x.data_ptr(), xb.data_ptr(), R, D, D, -1, S()),
+ "out-proj resid+xb": lambda: lib.hmm_op_gemm_bf16_resid_xb(a.data_ptr(), wo.data_ptr(), bo.data_ptr(), x.data_ptr(), xb.data_ptr(), part.data_ptr(), R, D, D, -1, S()),
  "fc2 resid": lambda: lib.hmm_op_gemm_bf16(big.data_ptr(), w2.data_ptr(), bb2.data_ptr(), x.data_ptr(), R, D, MLP, 2, S()),
- "fc2 resid+xb": lambda: lib.hmm_op_gemm_bf16_resid_xb(big.data_ptr(), w2.data_ptr(), bb2.data_ptr(), x.data_ptr(), xb.data_ptr(), R, D, MLP, -1, S()),
+ "fc2 resid+xb": lambda: lib.hmm_op_gemm_bf16_resid_xb(big.data_ptr(), w2.data_ptr(), bb2.data_ptr(), x.data_ptr(), xb.data_ptr(), part.data_ptr(), R, D, MLP, -1, S()),
  "fc1 bias+gelu": lambda: lib.hmm_op_gemm_bf16(a.data_ptr(), w1.data_ptr(), bb1.data_ptr(), big.data_ptr(), R, MLP, D, 1, S()),
  "fc1 ln+gelu": lambda: lib.hmm_op_gemm_bf16_ln(xb.data_ptr(), w1.data_ptr(), bb1.data_ptr(), big.data_ptr(), R, MLP, D, 1, rs.data_ptr(), 1, c1.data_ptr(), -1, S()),
  "fused qkv+attn": lambda: lib.hmm_op_qkv_attention_bf16(a.data_ptr(), wq.data_ptr(), bq.data_ptr(), qkv_cls.data_ptr(), big.data_ptr(), B, S()),
