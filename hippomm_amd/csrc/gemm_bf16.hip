@@ -430,6 +430,8 @@ extern "C" void hmm_probe_set_gemm_stamps(unsigned long long* p) { g_gemm_stamps
 #define HMM_STAMP(slot)
 #endif
 
+HMM_TUNABLE(int, g_gemm_skip_tail, 0)   // probe build: 1 = do not launch the peeled tail (what the tails cost in the forward)
+
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
@@ -588,6 +590,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         const int m_main = (tiles_m - peel) * 256;
         int rc = launch_gemm_pp_epi(A, W, bias, C, m_main, N, K, epi, aux, st);
         if (rc != HMM_OK) return rc;
+        if (g_gemm_skip_tail) return rc;                         // probe build only (timing upper bound; results are wrong)
         const bool c_bf16 = epi == HMM_EPI_BIAS_BF16 || epi == HMM_EPI_BIAS_GELU_BF16 || epi == HMM_EPI_LN_BF16 ||
                             epi == HMM_EPI_LN_GELU_BF16;
         GemmAux tail = aux;                                      // the per-row operands move with the rows
