@@ -324,9 +324,81 @@ def scan_bench(do_cpu):
                                          "best of 3 after a warm run; numpy/BLAS default threads"}
         out["parity_vs_oracle"] = {"top32_indices_equal": idx_gpu.cpu().tolist() == [int(i) for i in o_idx]}
         del host
+    out["retrieval"] = retrieval_bench(rows, do_cpu)
     del rows, store
     torch.cuda.empty_cache()
     return out
+
+
+def retrieval_bench(rows, do_cpu):
+    """The retrieval path as one latency (SURVEY 8f-1 + 8f-4): question string -> BPE ids -> text tower -> per-event top-5
+    over the resident store cut into 2000 events of 500 rows -> results on the host; hippocampal_memory.py:2173-2177 ->
+    :3143-3153 -> :3275-3277.  Beside it the reference's route on this host's cores: the fp32 oracle text tower and the
+    Python loop of one numpy scan per event."""
+    from hippomm_amd.encoder import HipTower, synthetic_state_dict
+    from hippomm_amd.tokenizer import SimpleTokenizer
+    from hippomm_amd.vector_ops import EventStore
+    n_events, per_event = 2000, SCAN_ROWS // 2000
+    events = EventStore.from_device_rows(rows, [per_event] * n_events)
+    tok = SimpleTokenizer("", merges=[])                     # byte-level ids (the upstream merge table is not in this image)
+    sd = synthetic_state_dict(("text",), seed=99)
+    tower = HipTower("text", sd)
+    question = "who opens the door after the phone rang?"
+    emb = torch.empty(1, 1024, device="cuda")
+
+    def ask():
+        ids = tok([question]).cuda()
+        tower.forward_into(ids, emb)
+        hits = events.top_k_per_event(emb[0], 5)             # reads the results back: this is the synchronisation
+        flat = [(float(s), e, int(i)) for e, (idx, sims) in enumerate(hits) for i, s in zip(idx, sims)]
+        flat.sort(key=lambda h: -h[0])
+        return flat[:5]
+
+    ask(); ask()
+    t = []
+    for _ in range(7):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        top = ask()
+        t.append(time.perf_counter() - t0)
+    t_tower = event_time_ms(lambda: tower.forward_into(tok([question]).cuda(), emb), 10, warmup=2)
+    q = emb[0].clone()
+    t_scan = event_time_ms(lambda: events.search_segments_device(q, events.offsets, 5), 10, warmup=2)
+    out = {"what": "question -> tokenizer -> text tower (24 blocks, batch 1) -> top-5 per event over 2000 events x 500 rows "
+                   "(one pass) -> best 5 hits on the host",
+           "ms_end_to_end": round(sorted(t)[len(t) // 2] * 1e3, 3), "ms_text_tower": round(t_tower, 3),
+           "ms_per_event_scan_all_events": round(t_scan, 3), "events": n_events, "rows": n_events * per_event}
+    if do_cpu:
+        from oracle import imagebind_oracle as ib
+        from oracle.vector_ops_oracle import top_k_cosine_similarity_oracle
+        st = {k: v.detach().float().cpu() for k, v in sd.items()}
+        ids = tok([question])
+        ib.text_forward(ids, st)
+        t0 = time.perf_counter()
+        ref_q = ib.text_forward(ids, st)
+        t_tower_cpu = time.perf_counter() - t0
+        cos = torch.nn.functional.cosine_similarity(emb.cpu(), ref_q, dim=1)
+        qh = q.cpu().numpy()
+        host = rows[: 200 * per_event].cpu().numpy()         # the reference's loop on a bounded sample: 200 of the 2000 events
+        t0 = time.perf_counter()
+        hits = [top_k_cosine_similarity_oracle(qh, host[e * per_event:(e + 1) * per_event], 5) for e in range(200)]
+        t_loop = (time.perf_counter() - t0) * (n_events / 200)
+        flat = [(float(s), e, int(i)) for e, (idx, sims) in enumerate(hits) for i, s in zip(idx, sims)]
+        flat.sort(key=lambda h: -h[0])
+        mine = sorted([h for h in _all_hits(events, q) if h[1] < 200], key=lambda h: -h[0])[:5]
+        out["cpu_reference"] = {"ms_text_tower_oracle": round(t_tower_cpu * 1e3, 1), "ms_python_loop_all_events": round(t_loop * 1e3, 1),
+                                "cores": os.cpu_count(), "sample": "fp32 oracle text tower, 1 query; numpy scan per event on 200 of the "
+                                "2000 events, scaled x10"}
+        out["parity_vs_oracle"] = {"text_embedding_cos": round(float(cos.min()), 7),
+                                   "top5_of_first_200_events_equal": [(e, i) for _, e, i in mine] == [(e, i) for _, e, i in flat[:5]]}
+        out["speedup_vs_cpu_reference"] = round((t_tower_cpu + t_loop) * 1e3 / out["ms_end_to_end"], 1)
+    del tower, sd
+    torch.cuda.empty_cache()
+    return out
+
+
+def _all_hits(events, q):
+    return [(float(s), e, int(i)) for e, (idx, sims) in enumerate(events.top_k_per_event(q, 5)) for i, s in zip(idx, sims)]
 
 
 def consolidation_bench(do_cpu):
@@ -686,6 +758,9 @@ def main():
             bad.append("all_reduced_rank_count")
         if "scan" in line and not line["scan"].get("parity_vs_oracle", {}).get("top32_indices_equal", True):
             bad.append("scan.parity_vs_oracle")
+        rp = line.get("scan", {}).get("retrieval", {}).get("parity_vs_oracle")
+        if rp and not (rp["top5_of_first_200_events_equal"] and 1 - rp["text_embedding_cos"] <= 2e-4):
+            bad.append("scan.retrieval.parity_vs_oracle")
         for tag in ("weak_1M_rows_per_gpu", "strong_1M_rows_total"):
             if "scan" in line and not line["scan"].get(tag, {}).get("indices_match_torch_where_separated", True):
                 bad.append(f"scan.{tag}")

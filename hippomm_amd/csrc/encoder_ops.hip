@@ -39,14 +39,22 @@ template <int NV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void layernorm_bf16_kernel(const float* __restrict__ x, size_t in_stride,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
-                                                             bf16_t* __restrict__ y, int rows, float eps) {
+                                                             bf16_t* __restrict__ y, int rows, float eps, int nt) {
     constexpr int D = 256 * NV;
     const int lane = threadIdx.x & 63;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {   // grid-stride
         const float* src = x + (size_t)row * in_stride;
         float4 v[NV];
+        if (nt) {                                            // the fp32 stream is read once per LayerNorm: keep it out of the caches
 #pragma unroll
-        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const float4*>(src + 4 * (64 * j + lane));
+            for (int j = 0; j < NV; ++j) {
+                const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 4 * (64 * j + lane)));
+                v[j] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const float4*>(src + 4 * (64 * j + lane));
+        }
         row_layernorm<NV>(v, gamma, beta, eps, lane);
         bf16_t* dst = y + (size_t)row * D;
 #pragma unroll
@@ -332,14 +340,17 @@ __global__ __launch_bounds__(256) void fold_ln_weights_kernel(const float* __res
     if (tid == 0) { c1[n] = (float)red[0][0]; c2[n] = (float)(red[1][0] + (double)bias[n]); }
 }
 
+HMM_TUNABLE(int, g_ln_nt_loads, 0)       // probe build: 1 = non-temporal loads of the fp32 residual stream in LayerNorm (A/B)
+
 int launch_layernorm_bf16(const float* x, size_t in_stride, const float* g, const float* b, bf16_t* y,
                           int rows, int D, float eps, hipStream_t st) {
     HMM_REQUIRE(D == 768 || D == 1024 || D == 1280, HMM_E_INVALID, "layernorm: D must be 768, 1024 or 1280, got %d", D);
     if (rows <= 0) return HMM_OK;
     int blocks = (rows + 3) / 4;
-    if (D == 768)       layernorm_bf16_kernel<3><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps);
-    else if (D == 1024) layernorm_bf16_kernel<4><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps);
-    else                layernorm_bf16_kernel<5><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps);
+    const int nt = g_ln_nt_loads && rows >= 4096;            // small launches (cls rows) are re-read from L2 right away
+    if (D == 768)       layernorm_bf16_kernel<3><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps, nt);
+    else if (D == 1024) layernorm_bf16_kernel<4><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps, nt);
+    else                layernorm_bf16_kernel<5><<<blocks, 256, 0, st>>>(x, in_stride, g, b, y, rows, eps, nt);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }

@@ -325,18 +325,19 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
         constexpr bool RESID = EPI == HMM_EPI_BIAS_RESID_F32 || EPI == HMM_EPI_BIAS_RESID_XB;
         float* C = static_cast<float*>(Cout);
         const int rsub = lane >> 4, chunk = lane & 15;
-        // Software-pipelined over the two 64-row halves: the residual rows of half 1 are requested as soon as half 0's
-        // accumulators are parked in the slab (their registers are free from then on), so they fly during half 0's
-        // read-add-store and half 1 never waits a full HBM latency (out-proj tile epilogue: 16.6 us before).
-        float4 xin[2][16];
-        auto load_resid = [&](int half) {
+        // Software-pipelined over four 32-row quarters: the residual rows of quarter q + 1 are requested before quarter q is
+        // read back, added and stored, so that a quarter never waits a full HBM latency, and only two quarters of residual
+        // (64 registers) are ever live beside the accumulators -- with both 64-row halves in flight (128 registers) the
+        // RESID_XB variant spilled 70 registers to scratch and took 1.6x as long (profiles/r3_resid_epilogue.json).
+        float4 xin[2][8];
+        auto load_resid = [&](int q) {                           // rows 32 q .. 32 q + 31 of the wave tile
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int m = m_wave + half * 64 + it * 4 + rsub;
-                xin[half][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int it = 0; it < 8; ++it) {
+                const int m = m_wave + q * 32 + it * 4 + rsub;
+                xin[q & 1][it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (m < M) {                                     // streamed once: non-temporal (out-proj -2 % in the tower, -12 % alone)
                     const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(C + (size_t)m * N + n_wave + chunk * 4));
-                    xin[half][it] = make_float4(t[0], t[1], t[2], t[3]);
+                    xin[q & 1][it] = make_float4(t[0], t[1], t[2], t[3]);
                 }
             }
         };
@@ -352,15 +353,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         };
-        auto drain = [&](int half) {                             // slab rows (+ residual) -> C, 256 B per 16 lanes
+        auto drain = [&](int q) {                                // slab rows (+ residual) -> C, 256 B per 16 lanes
             uint2 xb_even = make_uint2(0u, 0u);                   // RESID_XB: bf16 of the even iteration's row, kept for pairing
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int row = it * 4 + rsub;
+            for (int it = 0; it < 8; ++it) {
+                const int row = (q & 1) * 32 + it * 4 + rsub;     // row inside the 64-row slab
                 float4 v = *reinterpret_cast<const float4*>(slab + row * RS + chunk * 16);
-                const int m = m_wave + half * 64 + row;
+                const int m = m_wave + q * 32 + it * 4 + rsub;
                 if constexpr (RESID) {
-                    v.x += xin[half][it].x; v.y += xin[half][it].y; v.z += xin[half][it].z; v.w += xin[half][it].w;
+                    v.x += xin[q & 1][it].x; v.y += xin[q & 1][it].y; v.z += xin[q & 1][it].z; v.w += xin[q & 1][it].w;
                 }
                 if (m < M) {
                     if constexpr (RESID)
@@ -371,15 +372,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
                 if constexpr (EPI == HMM_EPI_BIAS_RESID_XB) {
                     // The bf16 image of the new residual rows, 16 B per lane: a lane holds 4 columns (8 B) of row `it` and of
                     // row `it + 1`; neighbours (chunk ^ 1) swap halves so that the even lane stores 8 columns of the first
-                    // row and the odd lane 8 columns of the second -- whole 128-B lines, half the store instructions (8-B
-                    // stores made the out-proj epilogue 51 us longer, 16-B ones ... see DESIGN.md 4.5).
+                    // row and the odd lane 8 columns of the second -- whole 128-B lines, half the store instructions.
                     bf16x4 o4 = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
                     {   // chunk statistics of this row's 64 columns (encoder_ops.h): leaf j = chunk, butterfly over the DPP row
                         const float b0 = (float)o4[0], b1 = (float)o4[1], b2 = (float)o4[2], b3 = (float)o4[3];
                         const float s = row16_sum(chunk_leaf_sum(b0, b1, b2, b3));
-                        const float q = row16_sum(chunk_leaf_sq(b0, b1, b2, b3, s * (1.0f / 64.0f)));
+                        const float q2 = row16_sum(chunk_leaf_sq(b0, b1, b2, b3, s * (1.0f / 64.0f)));
                         if (aux.part != nullptr && chunk == 0 && m < M)
-                            aux.part[(size_t)m * (N >> 6) + (n_wave >> 6)] = make_float2(s, q);
+                            aux.part[(size_t)m * (N >> 6) + (n_wave >> 6)] = make_float2(s, q2);
                     }
                     const uint2 cur = __builtin_bit_cast(uint2, o4);
                     if ((it & 1) == 0) {
@@ -391,21 +391,28 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
                         recv.x = (unsigned)__shfl_xor((int)send.x, 1, 64);
                         recv.y = (unsigned)__shfl_xor((int)send.y, 1, 64);
                         const int m_st = odd ? m : m - 4;         // odd lanes store row `it`, even lanes row `it - 1`
-                        const uint4 q = odd ? make_uint4(recv.x, recv.y, cur.x, cur.y) : make_uint4(xb_even.x, xb_even.y, recv.x, recv.y);
+                        const uint4 qd = odd ? make_uint4(recv.x, recv.y, cur.x, cur.y) : make_uint4(xb_even.x, xb_even.y, recv.x, recv.y);
                         if (m_st < M)
-                            *reinterpret_cast<uint4*>(aux.xb + (size_t)m_st * N + n_wave + (chunk & ~1) * 4) = q;
+                            *reinterpret_cast<uint4*>(aux.xb + (size_t)m_st * N + n_wave + (chunk & ~1) * 4) = qd;
                     }
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is re-used: reads must be done
+        };
+        auto slab_free = [&]() {                                 // the slab is re-used: its reads must be done
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         };
         if constexpr (RESID) load_resid(0);
         park(0);
         if constexpr (RESID) load_resid(1);
         drain(0);
-        park(1);
+        if constexpr (RESID) load_resid(2);
         drain(1);
+        slab_free();
+        park(1);
+        if constexpr (RESID) load_resid(3);
+        drain(2);
+        drain(3);
     }
 }
 

@@ -60,9 +60,10 @@ __device__ __forceinline__ void top64_desc(uint64_t* s, int n2) {
                 const uint64_t a = s[(2 * p) * 64 + lane], b = s[(2 * p + 1) * 64 + 63 - lane];
                 v = wave_bitonic_merge_desc(a > b ? a : b, lane);
             }
-            // chunk p is still being read as chunk 2p' or 2p'+1 by another wave of this round (only in the round p0 = 0;
-            // later rounds read chunks >= 2 n_waves and write chunks < 2 p0)
-            if (p0 == 0) __syncthreads();
+            // chunk p may still be read as chunk 2p' or 2p'+1 by a slower wave of this round: every wave finishes the
+            // reads of a round before any wave writes its result (a barrier per round; the rounds after it only read
+            // chunks >= 2 (p0 + n_waves), which this round does not write).  Holds for any n2, not only pairs <= 2 n_waves.
+            __syncthreads();
             if (p < pairs) s[p * 64 + lane] = v;
         }
         chunks = pairs;

@@ -171,8 +171,9 @@ def top_k_cosine_similarity(
     a: (1024,) query (numpy or torch); b: (N,1024) store (numpy, torch, or a resident
     FeatureStore; a 1-D b is one row, as at :173-174).  Returns (indices int64[k'],
     similarities[k']), k' = min(k, N), best first; similarities are float64 when either input was
-    float64 (numpy's promotion at :182) and float32 otherwise.  Ties: higher row index first;
-    a zero-norm row yields NaN and ranks first, as it does in the reference.
+    float64 (numpy's promotion at :182) and float32 otherwise.  Ties: higher row index first; a zero-norm
+    row yields NaN and ranks first, as in the reference.  (The reference leaves the order INSIDE a tie group to numpy's
+    unstable argsort; this total order is the library's own rule, include/hippomm_hip.h.)
     """
     store = b if isinstance(b, FeatureStore) else FeatureStore(b)
     a_is64 = (isinstance(a, np.ndarray) and a.dtype == np.float64) or (
@@ -199,6 +200,21 @@ class EventStore(FeatureStore):
         else:
             super().__init__(rows, dev)
         self.offsets = torch.tensor(np.concatenate([[0], np.cumsum(self.lengths)]), dtype=torch.int64, device=dev)
+
+    @classmethod
+    def from_device_rows(cls, rows: torch.Tensor, lengths) -> "EventStore":
+        """An EventStore over a (N,1024) fp32 matrix that is already resident (events = consecutive row ranges of the
+        given lengths); nothing is copied."""
+        self = cls.__new__(cls)
+        if rows.dim() != 2 or rows.shape[1] != FEATURE_DIM or rows.dtype != torch.float32 or not rows.is_contiguous():
+            raise ValueError("rows must be a contiguous (N,1024) fp32 tensor")
+        self.lengths = [int(n) for n in lengths]
+        if sum(self.lengths) != rows.shape[0]:
+            raise ValueError(f"event lengths sum to {sum(self.lengths)}, store has {rows.shape[0]} rows")
+        self.source_dtype = np.dtype(np.float32)
+        self.rows, self._ws, self._ws_key = rows, None, None
+        self.offsets = torch.tensor(np.concatenate([[0], np.cumsum(self.lengths)]), dtype=torch.int64, device=rows.device)
+        return self
 
     def top_k_per_event(self, query, k: int = 5):
         """[(indices int64[k_e], sims float32[k_e]) for every event], each exactly what

@@ -51,9 +51,13 @@ const char* hmm_last_error(void);
  *
  *   sims[i] = dot(store[i], q) / (||store[i]|| * ||q||)      fp32, one pass over the store
  *   result  = the k' = min(k, n_rows) rows with the largest sims, best first.
- *   Order on ties / NaN (the reference leaves these to numpy's argsort; this is what it was
- *   observed to return): NaN (zero-norm row or query) ranks above every number; among equal
- *   sims the HIGHER row index comes first; -0.0 == +0.0.
+ *   Order on ties / NaN: UNSPECIFIED in the reference -- it takes argsort(sims)[-k:][::-1] (vector_ops.py:185) and numpy's
+ *   default introsort is unstable, so which of several equal (or NaN) similarities survives the cut depends on the input
+ *   length and layout.  THIS library's rule is a total order: NaN (zero-norm row or query) ranks above every number; among
+ *   equal sims the HIGHER row index comes first; -0.0 == +0.0.  It reproduces what the reference returns on the golden
+ *   duplicate-row and zero-row cases (tests/golden/scan_golden.json) but not always: on live case 31 the reference
+ *   returns zero-norm row 12 of {12, 55} where this rule returns 55 (tests/test_gpu_live_golden.py checks values and
+ *   membership there, not the order inside a tie group).
  *
  *   store_dev  (n_rows, 1024) fp32 row-major, resident in HBM      query_dev (1024) fp32
  *   idx_out_dev int64[k'], sim_out_dev fp32[k'], n_out_dev int32[1] (= k')

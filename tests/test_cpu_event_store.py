@@ -22,6 +22,19 @@ def test_writer_is_byte_identical_to_the_reference():
     assert set(d["features"]) == {"vision", "audio"} and set(d["feature_times"]) == {"vision_times", "audio_times"}
 
 
+def test_fast_writer_equals_json_dumps_indent_2():
+    """The row-wise C-encoder path must give the bytes of json.dumps(to_dict(), indent=2) on anything an event can hold:
+    the golden event, NaN / inf / -0 / denormal-range values, an empty matrix, a 1-D feature, integer-valued lists."""
+    case = recipes.event_case()
+    assert es.event_json_text(case, fast=True) == es.event_json_text(case, fast=False) == GOLD.read_text()
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal((37, 1024)).astype(np.float32)
+    v[3, 5], v[4, 5], v[7, 7], v[8, 7], v[9, 0] = np.nan, np.inf, 1e-30, -0.0, 123456792.0
+    odd = dict(case, features={"vision": v, "vision_times": np.arange(37) * 0.5, "audio": np.zeros((0, 1024), np.float32),
+                               "audio_times": [], "depth": rng.standard_normal(1024).astype(np.float32), "ints": [[1, 2], [3, 4]]})
+    assert es.event_json_text(odd, fast=True) == json.dumps(es.event_to_dict(odd), indent=2)
+
+
 def test_json_round_trip_is_exact_in_fp32():
     case = recipes.event_case()
     feats, times = es.parse_event_features(GOLD)

@@ -44,7 +44,7 @@ def test_cfg5_on_one_gpu(cfg5_one_gpu):
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["unit"] == "frame-embeddings/s" and d["value"] > 0
     assert c["frames_total"] == 3600 and c["frames_per_rank"] == [3600] and "cfg5" in c["workload"]
     assert c["kept_equal_cpu_oracle_on_gathered_matrix"] is True
-    assert 100 <= c["kept_key_frames"] <= 3600              # 600 scenes of 6 frames: the selection really drops frames
+    assert 1 <= c["kept_key_frames"] < 3600                 # near-duplicate frames: the selection really drops frames
     assert abs(d["value"] - 3600 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1.0
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
 

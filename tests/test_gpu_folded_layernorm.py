@@ -124,8 +124,8 @@ def test_rowstat_finalize_on_rows_with_large_means(dim):
     mean = xb.mean(1)
     rstd = 1.0 / torch.sqrt(xb.var(1, unbiased=False) + 1e-6)
     rs = rs.double().cpu()
-    assert torch.allclose(rs[:, 0], rstd, rtol=5e-6, atol=0)
-    assert torch.allclose(rs[:, 1], rstd * mean, rtol=5e-6, atol=1e-6 * float((rstd * mean).abs().max()))
+    assert torch.allclose(rs[:, 0], rstd, rtol=2e-5, atol=0)
+    assert torch.allclose(rs[:, 1], rstd * mean, rtol=2e-5, atol=1e-6 * float((rstd * mean).abs().max()))
 
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])

@@ -3,8 +3,13 @@ by tests/golden/live_reference.py in the build container; inputs are rebuilt her
 Scan (hippomm/utils/vector_ops.py:151-188): the returned rows must be the reference's wherever its ranking is separated
 by more than the fp32 noise; inside runs of equal or near-equal similarities (exact duplicate rows, NaN rows) the order is
 the documented one (tests/test_gpu_scan.py) and only values and membership are compared.
-Selection (hippomm/core/hippocampal_memory.py:944-967): kept indices identical; cases whose nearest comparison sits inside
-the BLAS-order band (|S - thr| < 5e-6) are skipped, that band is pinned separately (tests/test_gpu_select.py)."""
+Selection (hippomm/core/hippocampal_memory.py:944-967): every case is run.  The HIP result must always equal the
+fp64-accumulated, round-once definition (select_key_frames_exact), and it must equal the reference's kept list whenever the
+nearest evaluated comparison is further than SELECT_BAND from the threshold.  SELECT_BAND = 4e-7 = 7 fp32 ulps at 0.9
+(ulp 6e-8): the reference's S is an sgemm of 1024-term dot products of unit rows, whose value moves by a few ulps with the
+summation order of the BLAS it runs on (hippocampal_memory.py:952, :958-961); the definition is within half an ulp of the
+exact value.  Inside the band the reference's own answer is host-dependent: agreement is printed, not asserted (none of
+the 60 committed cases is inside it; the three closest sit at 1.4e-6, 3.7e-6 and 4.2e-6 and agree)."""
 import json
 import sys
 from pathlib import Path
@@ -19,6 +24,7 @@ import live_cases  # noqa: E402
 pytestmark = pytest.mark.gpu
 GOLD = json.loads((HERE / "golden" / "live_golden.json").read_text())
 BAND = 1e-6
+SELECT_BAND = 4e-7
 
 
 @pytest.mark.filterwarnings("ignore:invalid value encountered")
@@ -56,11 +62,15 @@ def test_scan_matches_reference_results(seed):
 @pytest.mark.parametrize("seed", range(live_cases.N_SELECT))
 def test_selection_matches_reference_results(seed):
     from hippomm_amd.consolidation import select_key_frames
-    from oracle.consolidation_oracle import evaluated_margin
+    from oracle.consolidation_oracle import evaluated_margin, select_key_frames_exact
     f, t, thr = live_cases.select_case(seed)
     with np.errstate(invalid="ignore", divide="ignore"):
         margin = evaluated_margin(f, thr)
-    if margin <= 5e-6:
-        pytest.skip(f"nearest comparison {margin:.1e} from the threshold: inside the BLAS-order band")
+        exact = select_key_frames_exact(f, thr)
     kept = select_key_frames(f, t, thr)
-    assert kept.dtype == np.int64 and kept.tolist() == GOLD["select"][seed]
+    assert kept.dtype == np.int64 and kept.tolist() == exact.tolist()      # the definition, everywhere
+    if margin > SELECT_BAND:
+        assert kept.tolist() == GOLD["select"][seed]                         # the unmodified reference's answer
+    else:
+        print(f"seed {seed}: nearest comparison {margin:.1e} from the threshold (inside the sgemm-order band): "
+              f"{'agrees with' if kept.tolist() == GOLD['select'][seed] else 'differs from'} the reference's answer on the golden host")

@@ -1,0 +1,115 @@
+"""GPU: the retrieval path end to end (SURVEY 8f-1 + 8f-2 + 8f-4 together), as QARecallSystem runs it:
+
+    question string -> tokenizer -> text tower -> query (1024,)            hippocampal_memory.py:2173-2176
+    for every event: top_k_cosine_similarity(query, event.features, k=5)   hippocampal_memory.py:3143-3153
+    all hits sorted by similarity, best 5 kept                             hippocampal_memory.py:3275-3277
+
+here: SimpleTokenizer -> ImageBind.extract_features({'text': [...]}) -> build_event_store(memory_store dir) ->
+EventStore.top_k_per_event(k=5), against oracle/text_forward for the embedding and the scan oracle called per event on the
+matrices the reference's own reader yields (JSON -> float64).  Two stores: a memory_store DIRECTORY of 200 events written
+through save_event (JSON byte-identical to the reference's + sidecars; ~5 k rows: the JSON costs 29 bytes per stored value)
+and an in-memory EventStore of 250 events / 120 k rows for the same query."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import imagebind_oracle as ib
+from oracle.vector_ops_oracle import top_k_cosine_similarity_oracle
+
+pytestmark = pytest.mark.gpu
+QUESTION = "who opens the door after the phone rang?"
+
+
+def _ranked(per_event, keep=5):
+    """The caller's final step (:3261-3277): every hit of every event, best similarity first, keep 5."""
+    hits = [(float(s), e, int(i)) for e, (idx, sims) in enumerate(per_event) for i, s in zip(idx, sims)]
+    hits.sort(key=lambda h: -h[0])
+    return hits[:keep]
+
+
+@pytest.fixture(scope="module")
+def text_model():
+    from test_tokenizer import _learn_merges
+    from hippomm_amd.encoder import ImageBind, synthetic_state_dict
+    from hippomm_amd.tokenizer import SimpleTokenizer
+    tok = SimpleTokenizer("", merges=_learn_merges())
+    sd = synthetic_state_dict(("text",), seed=4321)
+    model = ImageBind(state_dict=sd, towers=("text",), tokenizer=tok)
+    st = {k: v.detach().float().cpu() for k, v in sd.items()}
+    return model, tok, st
+
+
+@pytest.fixture(scope="module")
+def query(text_model):
+    model, tok, st = text_model
+    emb = model.extract_features({"text": [QUESTION]}, ["text"])["text"]                 # (1, 1024) on the GPU
+    q = emb.cpu().numpy().flatten()                                                      # as :3130-3134
+    tokens = tok([QUESTION])
+    assert tokens.shape == (1, 77) and int(tokens[0].argmax()) == len(tok.encode(QUESTION)) + 1
+    want = ib.text_forward(tokens, st).numpy().flatten()                                 # fp32 oracle, all 24 blocks
+    cos = float(np.dot(q, want) / (np.linalg.norm(q) * np.linalg.norm(want)))
+    assert 1 - cos <= 2e-4, cos
+    assert abs(np.linalg.norm(q) - np.linalg.norm(want)) <= 1e-3 * np.linalg.norm(want)  # x exp(log_logit_scale)
+    return q
+
+
+def test_question_to_hits_over_a_memory_store_directory(tmp_path, query):
+    from hippomm_amd import event_store as es
+    rng = np.random.default_rng(11)
+    base = tmp_path / "memory_store"
+    index, sizes = {}, []
+    for e in range(200):
+        n = int(rng.integers(1, 48)) if e % 17 else 0                                    # a few events without frames
+        f = rng.standard_normal((n, 1024)).astype(np.float32)
+        if n > 6:
+            f[5] = f[2]                                                                   # a duplicated frame (tie)
+        vid = f"video_{e // 10:02d}"
+        event_id = f"{vid}_{e * 30000}"
+        path = base / "events" / vid / f"{event_id}.json"
+        es.save_event({"features": {"vision": f, "vision_times": np.arange(n) * 1.0}, "frames": [], "frame_times": [],
+                       "frame_captions": [], "audio_times": [], "audio_transcription": [], "holistic_audio_transcription": "",
+                       "summary": f"event {e}", "start_time": e * 30.0, "end_time": e * 30.0 + 29.0}, path)
+        index[event_id] = {"video_id": vid, "start_time": e * 30.0, "end_time": e * 30.0 + 29.0, "file_path": str(path)}
+        sizes.append(n)
+    (base / "event_index.json").write_text(json.dumps(index, indent=2))
+    store, ids = es.build_event_store(base, "vision")
+    assert ids == list(index) and store.lengths == sizes and sum(sizes) > 4000
+    got = store.top_k_per_event(query, 5)
+    want = []
+    for event_id, path in es.iter_event_files(base):
+        data = json.loads(path.read_text())                                              # the reference's reader: json.load +
+        rows = np.array(data["features"]["vision"])                                      # np.array(list) -> float64 (:387-395)
+        if rows.size == 0:
+            want.append((np.zeros(0, np.int64), np.zeros(0)))
+            continue
+        assert rows.dtype == np.float64
+        want.append(top_k_cosine_similarity_oracle(query, rows, 5))
+    assert len(got) == len(want) == 200
+    for (idx, sims), (w_idx, w_sims), n in zip(got, want, sizes):
+        assert idx.dtype == np.int64 and len(idx) == min(5, n)
+        np.testing.assert_allclose(sims, w_sims, rtol=0, atol=2e-6)
+        gaps = np.abs(np.diff(w_sims)) if len(w_sims) > 1 else np.array([1.0])
+        if len(w_sims) and gaps.min() > 4e-6:                                            # separated: the same rows
+            assert idx.tolist() == [int(i) for i in w_idx]
+        else:                                                                            # the duplicated frame: library's tie rule
+            assert sorted(np.round(sims, 5).tolist()) == sorted(np.round(np.asarray(w_sims, np.float32), 5).tolist())
+    top_got, top_want = _ranked(got), _ranked(want)
+    assert [(e, i) for _, e, i in top_got] == [(e, i) for _, e, i in top_want]
+    np.testing.assert_allclose([s for s, _, _ in top_got], [s for s, _, _ in top_want], rtol=0, atol=2e-6)
+
+
+def test_question_to_hits_over_250_events_and_120k_rows(query):
+    from hippomm_amd.vector_ops import EventStore
+    rng = np.random.default_rng(12)
+    sizes = [int(n) for n in rng.integers(200, 760, size=250)]
+    events = [rng.standard_normal((n, 1024), dtype=np.float32) for n in sizes]
+    assert sum(sizes) >= 100_000
+    got = EventStore(events).top_k_per_event(query, 5)
+    want = [top_k_cosine_similarity_oracle(query, ev, 5) for ev in events]               # the reference's loop, event by event
+    for (idx, sims), (w_idx, w_sims) in zip(got, want):
+        np.testing.assert_allclose(sims, w_sims, rtol=0, atol=2e-6)
+        if np.abs(np.diff(w_sims)).min() > 4e-6:
+            assert idx.tolist() == [int(i) for i in w_idx]
+    assert [(e, i) for _, e, i in _ranked(got)] == [(e, i) for _, e, i in _ranked(want)]

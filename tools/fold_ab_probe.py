@@ -14,25 +14,32 @@ from hippomm_amd.encoder import HipTower, synthetic_state_dict
 
 tower = HipTower("vision", synthetic_state_dict(("vision",), seed=1234))
 torch.cuda.empty_cache()
-configs = [("ln_kernel", dict(fold=0, stats=1, skip_tail=0)),
-           ("fold_pass", dict(fold=1, stats=0, skip_tail=0)),
-           ("fold_epi", dict(fold=1, stats=1, skip_tail=0)),
-           ("fold_epi_notail", dict(fold=1, stats=1, skip_tail=1)),
-           ("ln_kernel_notail", dict(fold=0, stats=1, skip_tail=1))]
+KNOBS = ("g_enc_fold_stats", "g_gemm_skip_tail", "g_ln_nt_loads", "g_gemm_walk")
+BASE = dict(fold=0, g_enc_fold_stats=1, g_gemm_skip_tail=0, g_ln_nt_loads=0, g_gemm_walk=0)
+W84, W65 = (8 << 8) | 4, (6 << 8) | 5
+configs_big = [("ln_kernel", {}), ("ln_kernel_ntload", dict(g_ln_nt_loads=1)), ("ln_kernel_walk8x4", dict(g_gemm_walk=W84)),
+               ("ln_kernel_walk6x5", dict(g_gemm_walk=W65)), ("ln_kernel_notail", dict(g_gemm_skip_tail=1)),
+               ("fold_epi", dict(fold=1)), ("fold_pass", dict(fold=1, g_enc_fold_stats=0)),
+               ("fold_epi_walk8x4", dict(fold=1, g_gemm_walk=W84)), ("fold_epi_walk6x5", dict(fold=1, g_gemm_walk=W65))]
+configs_small = [("ln_kernel", {}), ("fold_epi", dict(fold=1)), ("fold_pass", dict(fold=1, g_enc_fold_stats=0))]
 res = {}
-for B in (256, 32, 64, 128):
+for B in (256, 32, 128):
+    configs = configs_big if B == 256 else configs_small
     x = torch.randn(B, 3, 224, 224, device="cuda"); out = torch.empty(B, 1024, device="cuda")
     times = {n: [] for n, _ in configs}
     for rnd in range(4):
         for name, c in configs:
+            c = dict(BASE, **c)
             tower.set_folded_layernorm(bool(c["fold"]))
-            setter(lib, "g_enc_fold_stats")(c["stats"])
-            setter(lib, "g_gemm_skip_tail")(c["skip_tail"])
+            for k in KNOBS:
+                setter(lib, k)(c[k])
             times[name].append(event_ms(lambda: tower.forward_into(x, out), 4 if B >= 128 else 10, warmup=2))
     for name, _ in configs:
         t = sorted(times[name])
         res[f"B{B}_{name}"] = {"ms_median": round((t[1] + t[2]) / 2, 3), "ms_min": round(t[0], 3), "img_per_s": round(B / ((t[1] + t[2]) / 2) * 1e3)}
-        print(f"B={B} {name:18s} median {res[f'B{B}_{name}']['ms_median']:8.3f} ms  min {t[0]:8.3f}  {res[f'B{B}_{name}']['img_per_s']} img/s", flush=True)
-setter(lib, "g_gemm_skip_tail")(0); setter(lib, "g_enc_fold_stats")(1); tower.set_folded_layernorm(True)
+        print(f"B={B} {name:20s} median {res[f'B{B}_{name}']['ms_median']:8.3f} ms  min {t[0]:8.3f}  {res[f'B{B}_{name}']['img_per_s']} img/s", flush=True)
+for k in KNOBS:
+    setter(lib, k)(BASE[k])
+tower.set_folded_layernorm(True)
 if len(sys.argv) > 1:
     json.dump(res, open(sys.argv[1], "w"), indent=1)
