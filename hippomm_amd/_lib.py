@@ -61,6 +61,7 @@ _SIGNATURES = {
     "hmm_op_gemm_bf16_resid_xb": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     "hmm_op_rowstat_finalize": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr]),
     "hmm_op_qkv_attention_ln_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr, c_ptr, c_ptr]),
+    "hmm_op_qkv_attention_audio_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr]),
     "hmm_op_attention_causal_bf16": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     "hmm_op_scan_topk_only": (C.c_int, [c_ptr, C.c_int64, c_ptr, C.c_int, c_ptr, c_ptr]),
     "hmm_op_scan_sims": (C.c_int, [c_ptr, C.c_int64, c_ptr, c_ptr, c_ptr]),

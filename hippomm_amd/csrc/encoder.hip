@@ -527,6 +527,15 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
         HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
         HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, -1, st));
         HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, -1, st));
+    } else if (i + 1 < e->depth && e->fused_attention && e->tower == HMM_TOWER_AUDIO && D == 768 && e->heads == 12 && T == 229 &&
+               e->bias_kv) {
+        // audio: in_proj + attention in one kernel per (clip, head); every row of a clip fits the 256-row tile, so there is
+        // no cls side path.  Bitwise equal to the branch below.
+        HMM_TRY(qkv_attention_audio_bf16(a, w.qkv_w, w.qkv_b, w.bias_k, w.bias_v, big, n_img, st));
+        HMM_TRY(gemm_bf16(big, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, -1, st));
+        HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
+        HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, -1, st));
+        HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, -1, st));
     } else if (i + 1 < e->depth || text) {
         HMM_TRY(gemm_bf16(a, w.qkv_w, w.qkv_b, big, R, 3 * D, D, HMM_EPI_BIAS_BF16, -1, st));
         HMM_TRY(attention_bf16(big, a, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st, text));

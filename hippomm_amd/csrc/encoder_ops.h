@@ -74,6 +74,10 @@ int attention_bf16(const bf16_t* qkv, bf16_t* out, int batch, int tokens, int he
 int qkv_attention_bf16(const bf16_t* a, const bf16_t* w, const float* bias, const bf16_t* qkv_cls, bf16_t* out,
                        int n_img, hipStream_t st, const float2* rs = nullptr, const float* c1 = nullptr);
 
+// audio tower (D 768, 12 heads of 64, 229 tokens per clip, add_bias_kv): the same fusion, all 229 rows inside the tile
+int qkv_attention_audio_bf16(const bf16_t* a, const bf16_t* w, const float* bias, const float* bias_k, const float* bias_v,
+                             bf16_t* out, int n_clips, hipStream_t st);
+
 // last block: one query (the cls token) per (image, head); kv is [rows][2D] = [k | v]
 int attention_cls_bf16(const bf16_t* q_cls, const bf16_t* kv, bf16_t* out, int batch, int tokens, int heads,
                        int head_dim, const float* bias_k, const float* bias_v, hipStream_t st);

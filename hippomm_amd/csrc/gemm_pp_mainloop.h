@@ -41,16 +41,19 @@ constexpr int kPPHalf = 16384, kPPTile = 4 * kPPHalf;     // LDS: 2 K-tiles x 4 
 // The quadrants are issued in pairs, 32 MFMAs per burst: a K-tile has 4 barrier intervals, and the partner group's whole
 // read section (16 / 8 fragment reads + its DMA issue) fits under one 512-cycle burst.  (Round 1 ran one quadrant per
 // phase, 8 intervals per K-tile: same bits, 1-3 % slower in the tower.)
-// TAIL16 = true (fused in_proj + attention kernel): tile columns 240..255 do not exist -- the waves of the last wave-column
-// (wn == 3) skip the MFMAs of their last 16-column block (acc[..][3] stays zero) instead of multiplying padding.
-template <bool TAIL16 = false>
+// TAIL (fused in_proj + attention kernels): 1 = tile columns 240..255 do not exist -- the waves of the last wave-column
+// (wn == 3) skip the MFMAs of their last 16-column block (acc[..][3] stays zero) instead of multiplying padding;
+// 2 = tile columns 192..255 do not exist (heads of 64: q | k | v fill three wave-columns) -- the waves of the last
+// wave-column skip their fragment reads and MFMAs altogether and only keep staging and the barriers.
+template <int TAIL = 0>
 __device__ __forceinline__ void pp_mainloop(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                             const PPSources& src, int KT, char* smem, int lane, int wave,
                                             f32x4 (&acc)[8][4]) {
     constexpr int HALF = kPPHalf, TILE = kPPTile;
     constexpr int H_ALO = 0, H_AHI = HALF, H_BLO = 2 * HALF, H_BHI = 3 * HALF;
     const int wm = wave >> 2, wn = wave & 3;
-    const bool skip_tail = TAIL16 && wn == 3;                     // wave-uniform
+    const bool skip_tail = TAIL != 0 && wn == 3;                  // wave-uniform
+    const bool idle = TAIL == 2 && skip_tail;                     // this wave computes nothing
 #define HMM_STAGE(base, s, kt, buf, half)                                                                   \
     do {                                                                                                    \
         __builtin_amdgcn_global_load_lds(HMM_GLB_PTR((base) + (ptrdiff_t)(s[0] + (kt) * 64)),               \
@@ -64,18 +67,21 @@ __device__ __forceinline__ void pp_mainloop(const bf16_t* __restrict__ A, const 
     const char* b_rd = smem + (wn * 32 + (lane & 15)) * 128;
     bf16x8 af[4][2], blo[2][2], bhi[2][2];
 #define HMM_READ_A(buf, half)                                                                         \
+    if (!idle)                                                                                        \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                  \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
         af[mi][kh] = *reinterpret_cast<const bf16x8*>(a_rd + (buf) * TILE + (half) + mi * 2048 + (kh ? ck1 : ck0));
 #define HMM_READ_B(dst, buf, half)                                                                    \
+    if (!idle)                                                                                        \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                  \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
         dst[ni][kh] = *reinterpret_cast<const bf16x8*>(b_rd + (buf) * TILE + (half) + ni * 2048 + (kh ? ck1 : ck0));
 #define HMM_MFMA_QUAD(mo, no, bsrc)                                                                   \
+    if (!idle)                                                                                        \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                  \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
-        if (!(TAIL16 && (no) + ni == 3 && skip_tail))                                                 \
+        if (!(TAIL == 1 && (no) + ni == 3 && skip_tail))                                              \
             acc[(mo) + mi][(no) + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[ni][kh], af[mi][kh], \
                                                                                 acc[(mo) + mi][(no) + ni], 0, 0, 0);
 #define HMM_BAR()                              \

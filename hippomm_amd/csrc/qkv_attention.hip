@@ -1,4 +1,6 @@
-// Fused QKV projection + attention for the ImageBind-huge VISION tower on gfx950 (D = 1280, 16 heads x 80, 257 tokens).
+// Fused QKV projection + attention for the ImageBind-huge VISION tower (D = 1280, 16 heads x 80, 257 tokens) and AUDIO tower
+// (D = 768, 12 heads x 64, 229 tokens + the add_bias_kv key) on gfx950; the text below describes the vision geometry, the
+// audio one differs as `AudioGeo` says.
 // Replaces, inside one transformer block, nn.MultiheadAttention's in_proj + scaled-dot-product attention
 // (upstream imagebind/models/transformer.py, called through foundation_models.py:131); the out_proj stays a GEMM.
 //
@@ -26,82 +28,105 @@
 
 namespace hmm {
 
-constexpr int kFD = 1280, kFH = 16, kFDH = 80, kFT = 257, kFNKT = 9;
-using FusedCfg = AttnCfg<kFDH, kFNKT>;
-constexpr int kFQRow = kFDH * 2 + 16;                                  // Q image row stride (as K rows: conflict-free b128)
-constexpr int kFQOff = FusedCfg::K_BYTES + FusedCfg::V_BYTES;          // Q image behind K and V
-constexpr int kFXOff = kFQOff + ((kFT * kFQRow + 15) / 16) * 16;       // cooperative-query scratch
-constexpr int kFLds = kFXOff + FusedCfg::X_BYTES;                      // 154,176 B (> the 131,072 B of GEMM staging)
-static_assert(kFLds >= 2 * kPPTile && kFLds <= 160 * 1024, "LDS plan of the fused kernel");
+// Geometry of one tower's fused kernel.  The projection tile is always 256 token rows x 256 columns [q_h | k_h | v_h | unused]:
+//   vision: 257 tokens, 16 heads x 80 -> rows = tokens 1..256 (token 0, the cls row, arrives through qkv_cls), 240 columns
+//           used (pp_mainloop<1> skips the last 16);
+//   audio:  229 tokens, 12 heads x 64, add_bias_kv -> rows = tokens 0..228 (+27 clamped rows whose results are dropped), 192
+//           columns used: q, k and v are one wave-column each and the fourth computes nothing (pp_mainloop<2>); the learned
+//           bias_k / bias_v row is appended to the K / V images as key 229.
+struct VisionGeo { static constexpr int D = 1280, H = 16, DH = 80, T = 257, NKT = 9, ROW0 = 1, TAIL = 1; static constexpr bool CLS_OUTSIDE = true, BIAS_KV = false; };
+struct AudioGeo  { static constexpr int D = 768,  H = 12, DH = 64, T = 229, NKT = 8, ROW0 = 0, TAIL = 2; static constexpr bool CLS_OUTSIDE = false, BIAS_KV = true; };
+
+template <class G>
+struct FusedPlan {
+    using Cfg = AttnCfg<G::DH, G::NKT>;
+    static constexpr int QRow = G::DH * 2 + 16;                          // Q image row stride (as K rows: conflict-free b128)
+    static constexpr int QOff = Cfg::K_BYTES + Cfg::V_BYTES;             // Q image behind K and V
+    static constexpr int XOff = QOff + ((G::T * QRow + 15) / 16) * 16;   // cooperative-query scratch
+    static constexpr int Used = XOff + Cfg::X_BYTES;                     // vision: 154,176 B (> the 131,072 B of GEMM staging)
+    static constexpr int Lds = Used > 2 * kPPTile ? Used : 2 * kPPTile;
+    static_assert(Lds <= 160 * 1024, "LDS plan of the fused kernel");
+    static_assert(G::T + (G::BIAS_KV ? 1 : 0) <= Cfg::NKEY && G::T - G::ROW0 <= 256 && 3 * G::DH <= 256, "tile geometry");
+};
 
 // LNF (folded LayerNorm, encoder.hip): `a` is the bf16 image of the residual stream, `w` = bf16(gamma (.) in_proj_weight),
 // `bias` = c2 and the projection value is fma(rs.x, acc, fma(-rs.y, c1, c2)) with rs[row] = (rstd, rstd * mean) -- the same
 // expression as gemm_bf16's HMM_EPI_LN_BF16 epilogue, so the two routes stay bitwise equal.
-template <bool LNF>
+template <class G, bool LNF>
 __global__ __launch_bounds__(512) void qkv_attention_kernel(
-    const bf16_t* __restrict__ a /* [n_img*257][1280] LayerNorm output */, const bf16_t* __restrict__ w /* [3840][1280] */,
-    const float* __restrict__ bias /* [3840] */, const bf16_t* __restrict__ qkv_cls /* [n_img][3840] */,
-    bf16_t* __restrict__ out /* [n_img*257][1280] */, int n_img, float scale_log2e,
-    const float2* __restrict__ rs /* [n_img*257] */, const float* __restrict__ c1 /* [3840] */) {
+    const bf16_t* __restrict__ a /* [n_img*T][D] LayerNorm output */, const bf16_t* __restrict__ w /* [3D][D] */,
+    const float* __restrict__ bias /* [3D] */, const bf16_t* __restrict__ qkv_cls /* [n_img][3D], CLS_OUTSIDE only */,
+    bf16_t* __restrict__ out /* [n_img*T][D] */, int n_img, float scale_log2e,
+    const float2* __restrict__ rs /* [n_img*T] */, const float* __restrict__ c1 /* [3D] */,
+    const float* __restrict__ bias_k /* [D], BIAS_KV only */, const float* __restrict__ bias_v) {
+    using P = FusedPlan<G>;
+    using Cfg = typename P::Cfg;
+    constexpr int kD = G::D, kH = G::H, kDH = G::DH, kT = G::T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int n = blockIdx.x >> 3;
-    const int b_lin = (blockIdx.x & 7) + 8 * (n / kFH);
-    const int h = n % kFH;
+    const int b_lin = (blockIdx.x & 7) + 8 * (n / kH);
+    const int h = n % kH;
     if (b_lin >= n_img) return;
     const int b = n_img - 1 - b_lin;
 
-    // ---- 1. projection tile: rows = the image's 256 patch tokens, columns = [q_h | k_h | v_h | 16 unused] -------------
+    // ---- 1. projection tile: rows = the sample's tokens ROW0 .. ROW0+255, columns = [q_h | k_h | v_h | unused] ----------
     PPSources src;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int lr = (wave + 8 * j) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((lr >> 1) & 7);
         const int arow = (lr & 63) + (lr >> 6) * 128;
-        const int tok = b * kFT + 1 + arow;                              // token 0 is the cls row (handled below)
-        src.alo[j] = tok * kFD + c * 8;
-        src.ahi[j] = (tok + 64) * kFD + c * 8;
+        auto tok_row = [&](int r) {                                      // tile row -> row of `a` (clamped: results dropped)
+            const int t = G::ROW0 + r;
+            return b * kT + (t < kT ? t : kT - 1);
+        };
+        src.alo[j] = tok_row(arow) * kD + c * 8;
+        src.ahi[j] = tok_row(arow + 64) * kD + c * 8;
         const int bcol = (lr >> 5) * 64 + (lr & 31);
         auto wrow = [&](int col) {                                       // tile column -> row of in_proj_weight
-            const int part = col / kFDH, d = col - part * kFDH;
-            return part < 3 ? part * kFD + h * kFDH + d : h * kFDH;      // columns 240..255: any valid row, results unused
+            const int part = col / kDH, d = col - part * kDH;
+            return part < 3 ? part * kD + h * kDH + d : h * kDH;         // unused columns: any valid row, results unused
         };
-        src.blo[j] = wrow(bcol) * kFD + c * 8;
-        src.bhi[j] = wrow(bcol + 32) * kFD + c * 8;
+        src.blo[j] = wrow(bcol) * kD + c * 8;
+        src.bhi[j] = wrow(bcol + 32) * kD + c * 8;
     }
     f32x4 acc[8][4];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    pp_mainloop<true>(a, w, src, kFD >> 6, smem, lane, wave, acc);     // columns 240..255: no MFMAs
+    pp_mainloop<G::TAIL>(a, w, src, kD >> 6, smem, lane, wave, acc);   // the unused columns: no MFMAs
 
     // ---- 2. accumulators -> Q / K / V images (the staging buffers are dead: see pp_mainloop) --------------------------
     char* k_lds = smem;
-    char* v_lds = smem + FusedCfg::K_BYTES;
-    char* q_lds = smem + kFQOff;
+    char* v_lds = smem + Cfg::K_BYTES;
+    char* q_lds = smem + P::QOff;
     {
         const int fr = lane & 15, fq = lane >> 4;
         float2 rsv[8];
         if constexpr (LNF) {
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) rsv[mi] = rs[(size_t)b * kFT + 1 + wm * 128 + mi * 16 + fr];
+            for (int mi = 0; mi < 8; ++mi) {
+                const int tok = G::ROW0 + wm * 128 + mi * 16 + fr;
+                rsv[mi] = rs[(size_t)b * kT + (tok < kT ? tok : kT - 1)];
+            }
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int col = wn * 64 + ni * 16 + 4 * fq;                  // 4 consecutive tile columns, never across a part
-            const int part = col / kFDH, d = col - part * kFDH;
-            if (part < 3) {                                              // wave-uniform per (wn, ni) except the last group
-                const float4 bv = *reinterpret_cast<const float4*>(bias + part * kFD + h * kFDH + d);
+            const int part = col / kDH, d = col - part * kDH;
+            if (part < 3) {                                              // wave-uniform per (wn, ni) except vision's last group
+                const float4 bv = *reinterpret_cast<const float4*>(bias + part * kD + h * kDH + d);
                 float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (LNF) cv = *reinterpret_cast<const float4*>(c1 + part * kFD + h * kFDH + d);
+                if constexpr (LNF) cv = *reinterpret_cast<const float4*>(c1 + part * kD + h * kDH + d);
                 char* img = part == 0 ? q_lds : (part == 1 ? k_lds : v_lds);
-                const int stride = part == 0 ? kFQRow : (part == 1 ? FusedCfg::KROW : FusedCfg::VROW);
+                const int stride = part == 0 ? P::QRow : (part == 1 ? Cfg::KROW : Cfg::VROW);
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) {
-                    const int tok = 1 + wm * 128 + mi * 16 + fr;
+                    const int tok = G::ROW0 + wm * 128 + mi * 16 + fr;
                     const f32x4 v = acc[mi][ni];
                     bf16x4 o4;
                     if constexpr (LNF)
@@ -109,23 +134,34 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
                                     (bf16_t)ln_fold(v[2], rsv[mi], cv.z, bv.z), (bf16_t)ln_fold(v[3], rsv[mi], cv.w, bv.w)};
                     else
                         o4 = bf16x4{(bf16_t)(v[0] + bv.x), (bf16_t)(v[1] + bv.y), (bf16_t)(v[2] + bv.z), (bf16_t)(v[3] + bv.w)};
-                    *reinterpret_cast<bf16x4*>(img + tok * stride + d * 2) = o4;
+                    if (G::ROW0 + 255 < kT || tok < kT)                  // tile rows past the last token are dropped
+                        *reinterpret_cast<bf16x4*>(img + tok * stride + d * 2) = o4;
                 }
             }
         }
-        // token 0 (cls): its q | k | v slices come from the caller's small GEMM; 3 parts x 10 chunks of 16 B
-        if (tid < 30) {
-            const int part = tid / 10, ch = tid - part * 10;
-            const uint4 v = *reinterpret_cast<const uint4*>(qkv_cls + (size_t)b * (3 * kFD) + part * kFD + h * kFDH + ch * 8);
-            char* img = part == 0 ? q_lds : (part == 1 ? k_lds : v_lds);
-            *reinterpret_cast<uint4*>(img + ch * 16) = v;
+        if constexpr (G::CLS_OUTSIDE) {
+            // token 0 (cls): its q | k | v slices come from the caller's small GEMM; 3 parts x DH/8 chunks of 16 B
+            constexpr int CH = kDH / 8;
+            if (tid < 3 * CH) {
+                const int part = tid / CH, ch = tid - part * CH;
+                const uint4 v = *reinterpret_cast<const uint4*>(qkv_cls + (size_t)b * (3 * kD) + part * kD + h * kDH + ch * 8);
+                char* img = part == 0 ? q_lds : (part == 1 ? k_lds : v_lds);
+                *reinterpret_cast<uint4*>(img + ch * 16) = v;
+            }
         }
-        // key rows T .. NKEY-1: zeros
-        constexpr int CPR = kFDH / 8;
-        for (int idx = kFT * CPR + tid; idx < FusedCfg::NKEY * CPR; idx += 512) {
+        constexpr int LK = kT + (G::BIAS_KV ? 1 : 0);
+        if constexpr (G::BIAS_KV) {                                      // the add_bias_kv position: key row T
+            if (tid < kDH) {
+                *reinterpret_cast<bf16_t*>(k_lds + kT * Cfg::KROW + tid * 2) = (bf16_t)bias_k[h * kDH + tid];
+                *reinterpret_cast<bf16_t*>(v_lds + kT * Cfg::VROW + tid * 2) = (bf16_t)bias_v[h * kDH + tid];
+            }
+        }
+        // key rows LK .. NKEY-1: zeros
+        constexpr int CPR = kDH / 8;
+        for (int idx = LK * CPR + tid; idx < Cfg::NKEY * CPR; idx += 512) {
             const int row = idx / CPR, c = idx - row * CPR;
-            *reinterpret_cast<uint4*>(k_lds + row * FusedCfg::KROW + c * 16) = make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(v_lds + row * FusedCfg::VROW + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(k_lds + row * Cfg::KROW + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(v_lds + row * Cfg::VROW + c * 16) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
     __syncthreads();
@@ -133,35 +169,44 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
     // ---- 3. attention on the images ------------------------------------------------------------------------------------
     const int r = lane & 31, hh = lane >> 5;
     auto load_q = [&](int row, int ks) {
-        return *reinterpret_cast<const bf16x8*>(q_lds + row * kFQRow + hh * 16 + ks * 32);
+        return *reinterpret_cast<const bf16x8*>(q_lds + row * P::QRow + hh * 16 + ks * 32);
     };
-    bf16x8 qf[FusedCfg::KS];
+    bf16x8 qf[Cfg::KS];
     {
         const int qrow = wave * 32 + r;
-        const int qr = qrow < kFT ? qrow : kFT - 1;
+        const int qr = qrow < kT ? qrow : kT - 1;
 #pragma unroll
-        for (int ks = 0; ks < FusedCfg::KS; ++ks) qf[ks] = load_q(qr, ks);
+        for (int ks = 0; ks < Cfg::KS; ++ks) qf[ks] = load_q(qr, ks);
     }
-    attention_core<kFDH, kFNKT>(k_lds, v_lds, reinterpret_cast<float*>(smem + kFXOff), load_q, qf,
-                                out + (size_t)b * kFT * kFD + h * kFDH, kFT, kFT, kFD, scale_log2e, false);
+    attention_core<kDH, G::NKT>(k_lds, v_lds, reinterpret_cast<float*>(smem + P::XOff), load_q, qf,
+                                out + (size_t)b * kT * kD + h * kDH, kT, kT + (G::BIAS_KV ? 1 : 0), kD, scale_log2e, false);
+}
+
+template <class G, bool LNF>
+static int launch_fused(const bf16_t* a, const bf16_t* w, const float* bias, const bf16_t* qkv_cls, bf16_t* out, int n_img,
+                        hipStream_t st, const float2* rs, const float* c1, const float* bias_k, const float* bias_v) {
+    HMM_REQUIRE(n_img >= 1 && (int64_t)n_img * G::T * G::D < (1ll << 31), HMM_E_INVALID, "qkv_attention: n_img=%d out of range", n_img);
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)G::DH);
+    const int grid = 8 * ((n_img + 7) / 8) * G::H;
+    auto kern = qkv_attention_kernel<G, LNF>;
+    HMM_ENSURE_DYN_LDS(kern, FusedPlan<G>::Lds);
+    kern<<<grid, 512, FusedPlan<G>::Lds, st>>>(a, w, bias, qkv_cls, out, n_img, scale_log2e, rs, c1, bias_k, bias_v);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
 }
 
 int qkv_attention_bf16(const bf16_t* a, const bf16_t* w, const float* bias, const bf16_t* qkv_cls, bf16_t* out,
                        int n_img, hipStream_t st, const float2* rs, const float* c1) {
     HMM_REQUIRE(a && w && bias && qkv_cls && out, HMM_E_INVALID, "qkv_attention: null pointer");
     HMM_REQUIRE((rs == nullptr) == (c1 == nullptr), HMM_E_INVALID, "qkv_attention: row statistics and c1 go together");
-    HMM_REQUIRE(n_img >= 1 && (int64_t)n_img * kFT * kFD < (1ll << 31), HMM_E_INVALID, "qkv_attention: n_img=%d out of range", n_img);
-    const float scale_log2e = 1.4426950408889634f / sqrtf((float)kFDH);
-    const int grid = 8 * ((n_img + 7) / 8) * kFH;
-    if (rs) {
-        HMM_ENSURE_DYN_LDS(qkv_attention_kernel<true>, kFLds);
-        qkv_attention_kernel<true><<<grid, 512, kFLds, st>>>(a, w, bias, qkv_cls, out, n_img, scale_log2e, rs, c1);
-    } else {
-        HMM_ENSURE_DYN_LDS(qkv_attention_kernel<false>, kFLds);
-        qkv_attention_kernel<false><<<grid, 512, kFLds, st>>>(a, w, bias, qkv_cls, out, n_img, scale_log2e, nullptr, nullptr);
-    }
-    HMM_LAUNCH_CHECK();
-    return HMM_OK;
+    if (rs) return launch_fused<VisionGeo, true>(a, w, bias, qkv_cls, out, n_img, st, rs, c1, nullptr, nullptr);
+    return launch_fused<VisionGeo, false>(a, w, bias, qkv_cls, out, n_img, st, nullptr, nullptr, nullptr, nullptr);
+}
+
+int qkv_attention_audio_bf16(const bf16_t* a, const bf16_t* w, const float* bias, const float* bias_k, const float* bias_v,
+                             bf16_t* out, int n_clips, hipStream_t st) {
+    HMM_REQUIRE(a && w && bias && bias_k && bias_v && out, HMM_E_INVALID, "qkv_attention_audio: null pointer");
+    return launch_fused<AudioGeo, false>(a, w, bias, nullptr, out, n_clips, st, nullptr, nullptr, bias_k, bias_v);
 }
 
 }  // namespace hmm
@@ -182,4 +227,12 @@ extern "C" int hmm_op_qkv_attention_ln_bf16(const uint16_t* xb_dev, const uint16
     return qkv_attention_bf16(reinterpret_cast<const bf16_t*>(xb_dev), reinterpret_cast<const bf16_t*>(wf_dev), c2_dev,
                               reinterpret_cast<const bf16_t*>(qkv_cls_dev), reinterpret_cast<bf16_t*>(out_dev), n_img,
                               static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(rs_dev), c1_dev);
+}
+
+extern "C" int hmm_op_qkv_attention_audio_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
+                                               const float* bias_k_dev, const float* bias_v_dev, uint16_t* out_dev,
+                                               int n_clips, hmm_stream_t stream) {
+    return qkv_attention_audio_bf16(reinterpret_cast<const bf16_t*>(a_dev), reinterpret_cast<const bf16_t*>(w_dev), bias_dev,
+                                    bias_k_dev, bias_v_dev, reinterpret_cast<bf16_t*>(out_dev), n_clips,
+                                    static_cast<hipStream_t>(stream));
 }

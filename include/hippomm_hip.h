@@ -250,6 +250,14 @@ int hmm_op_attention_bf16(const uint16_t* qkv_dev, uint16_t* out_dev, int batch,
  * Bitwise equal to hmm_op_gemm_bf16(HMM_EPI_BIAS_BF16) + hmm_op_attention_bf16. */
 int hmm_op_qkv_attention_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
                               const uint16_t* qkv_cls_dev, uint16_t* out_dev, int n_img, hmm_stream_t stream);
+/* The same fusion for the audio tower (D = 768, 12 heads of 64, 229 tokens per clip, nn.MultiheadAttention add_bias_kv):
+ * a_dev [n_clips*229][768] bf16, w_dev [2304][768] bf16 + bias_dev [2304], bias_k_dev / bias_v_dev [768] fp32 (the learned
+ * extra key / value position), out_dev [n_clips*229][768] bf16.  All 229 rows of a clip sit inside the kernel's 256-row
+ * tile, so there is no separate cls projection.  Bitwise equal to hmm_op_gemm_bf16(HMM_EPI_BIAS_BF16) + hmm_op_attention_bf16
+ * with the same bias_k / bias_v. */
+int hmm_op_qkv_attention_audio_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
+                                    const float* bias_k_dev, const float* bias_v_dev, uint16_t* out_dev, int n_clips,
+                                    hmm_stream_t stream);
 /* Folded-LayerNorm pieces (hmm_encoder_set_folded_layernorm), exported for the parity tests:
  *   hmm_op_rowstat_bf16       rs[r] = (rstd, rstd * mean) of row r of xb [rows][dim] bf16 (dim = 768 / 1024 / 1280), eps inside
  *                             the square root as nn.LayerNorm;

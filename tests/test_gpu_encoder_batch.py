@@ -122,6 +122,22 @@ def test_fused_attention_option_is_bitwise_neutral(batch):
     _check(fused[:2], ib.vision_forward(x[:2].cpu(), st, spec), what=f"vision depth3 B={batch} fused attention")
 
 
+@pytest.mark.parametrize("batch", [2, 24])
+def test_fused_attention_option_is_bitwise_neutral_audio(batch):
+    """Audio tower: in_proj + attention as one kernel per (clip, head) (default) against QKV GEMM + attention kernel."""
+    from hippomm_amd.encoder import HipTower
+    spec = ib.reduced(ib.AUDIO_HUGE, 3)
+    st = ib.synthetic_state(spec, seed=22, init="rich")
+    mels = torch.randn(batch, 3, 1, 128, 204, generator=torch.Generator().manual_seed(9))
+    tower = HipTower("audio", st, depth=3)
+    fused = tower(mels)
+    tower.set_fused_attention(False)
+    plain = tower(mels)
+    tower.set_fused_attention(True)
+    assert torch.equal(fused, plain)
+    _check(fused[:2], ib.audio_forward(mels[:2], st, spec), scale=20.0, what=f"audio depth3 B={batch} fused attention")
+
+
 def test_full_depth_vision_batch256_bitwise_batch_invariance():
     """32 blocks at BASELINE cfg 2: the benchmarked configuration equals the oracle-checked small-batch path bit for bit,
     and its first frames match the fp32 oracle."""

@@ -306,3 +306,38 @@ def test_fused_qkv_attention_equals_gemm_plus_attention(n_img):
     want = (torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1) @ v).permute(0, 2, 1, 3).reshape(n_img * T, D)
     tol = 2.0 ** -8 * want.abs() + 2.0 ** -8 * v.abs().max() + 1e-4
     assert not ((one.float().cpu() - want).abs() > tol).any()
+
+
+@pytest.mark.parametrize("n_clips", [1, 5, 12])
+def test_fused_qkv_attention_audio_equals_gemm_plus_attention(n_clips):
+    """hmm_op_qkv_attention_audio_bf16 (audio tower: 229 tokens, 12 heads of 64, add_bias_kv; all rows of a clip inside the
+    kernel's 256-row tile, the fourth wave-column idle) against the QKV GEMM + attention kernel it replaces: BITWISE equal,
+    and close to fp32 torch on the bf16-rounded qkv with the bias_k / bias_v position appended."""
+    L, lib = _lib()
+    T, D, H, dh = 229, 768, 12, 64
+    g = torch.Generator().manual_seed(300 + n_clips)
+    a = _bf16(torch.randn(n_clips * T, D, generator=g))
+    w = _bf16(torch.randn(3 * D, D, generator=g) * 0.04)
+    bias = torch.randn(3 * D, generator=g) * 0.1
+    bk, bv = torch.randn(D, generator=g) * 0.5, torch.randn(D, generator=g) * 0.5
+    ad, wd, bd, bkd, bvd = a.cuda(), w.cuda(), bias.cuda(), bk.cuda(), bv.cuda()
+    qkv = torch.empty(n_clips * T, 3 * D, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_gemm_bf16(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), qkv.data_ptr(), n_clips * T, 3 * D, D,
+                                 EPI_BIAS_BF16, L.stream_ptr()), "gemm")
+    two = torch.full((n_clips * T, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_attention_bf16(qkv.data_ptr(), two.data_ptr(), n_clips, T, H, dh, bkd.data_ptr(), bvd.data_ptr(),
+                                      L.stream_ptr()), "attention")
+    one = torch.full((n_clips * T + 1, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_qkv_attention_audio_bf16(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), bkd.data_ptr(), bvd.data_ptr(),
+                                                one.data_ptr(), n_clips, L.stream_ptr()), "qkv_attention_audio")
+    assert torch.isnan(one[-1].float()).all()                         # nothing past the last clip's rows is written
+    one = one[:-1]
+    assert torch.isfinite(one.float()).all()
+    assert torch.equal(one, two), f"max diff {(one.float() - two.float()).abs().max().item()}"
+    q, k, v = qkv.float().cpu().reshape(n_clips, T, 3, H, dh).unbind(2)
+    q, k, v = (t.permute(0, 2, 1, 3) for t in (q, k, v))
+    k = torch.cat([k, _bf16(bk).float().reshape(1, H, 1, dh).expand(n_clips, H, 1, dh)], dim=2)
+    v = torch.cat([v, _bf16(bv).float().reshape(1, H, 1, dh).expand(n_clips, H, 1, dh)], dim=2)
+    want = (torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1) @ v).permute(0, 2, 1, 3).reshape(n_clips * T, D)
+    tol = 2.0 ** -8 * want.abs() + 2.0 ** -8 * v.abs().max() + 1e-4
+    assert not ((one.float().cpu() - want).abs() > tol).any()
