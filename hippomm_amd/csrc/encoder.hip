@@ -24,6 +24,8 @@
 
 namespace hmm {
 
+HMM_TUNABLE(int, g_enc_fold_default, 0)  // 1 = a vision tower starts with LayerNorm folded (hmm_encoder_set_folded_layernorm switches it)
+
 enum PackKind { PACK_F32, PACK_BF16, PACK_FOLD_CONV3D };
 
 struct ParamSlot {
@@ -345,7 +347,7 @@ extern "C" int hmm_encoder_missing_params(hmm_encoder* e) {
         if (all) {
             (void)hipFree(e->fold_stage);               // synchronises the device: the fold kernels are done
             e->fold_stage = nullptr;
-            e->fold_ln = true;
+            e->fold_ln = g_enc_fold_default != 0;       // built and parity-tested, but not faster: opt-in
         }
     }
     return missing;

@@ -264,16 +264,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
 // same shape.  fp32 outputs go in two 64-row halves to fit the slab.
 constexpr int kEpiSlab = 18432;                      // per-wave LDS slab: 128 rows x 144 B (bf16) / 64 x 272 B (fp32)
 
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const float* __restrict__ bias,
-                                                  void* __restrict__ Cout, int M, int N, int m_wave, int n_wave,
-                                                  char* slab, int lane, const GemmAux& aux) {
+// GUARD = false: the wave's 128 rows all exist (m_wave + 128 <= M, every tile but the last row tile): no per-row
+// predicates, so the compiler batches the slab reads and keeps the loads / stores back to back.  Addresses are a
+// wave-uniform base (C + m_wave * N + n_wave, scalar registers) plus a 32-bit per-lane byte offset; each row step adds a
+// uniform amount.  (With per-row guards and 64-bit per-lane addresses the fp32 epilogue was 1,400 instructions per wave and
+// waited for every slab read on its own; RESID_XB 3,500.)
+template <int EPI, bool GUARD>
+__device__ __forceinline__ void gemm_epilogue_lds_body(f32x4 (&acc)[8][4], const float4 (&bv)[4], void* __restrict__ Cout,
+                                                       int M, int N, int m_wave, int n_wave, char* slab, int lane,
+                                                       const GemmAux& aux) {
     const int fr = lane & 15, fq = lane >> 4;
-    float4 bv[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-        bv[ni] = bias ? *reinterpret_cast<const float4*>(bias + n_wave + ni * 16 + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
-
+    const int rows_left = M - m_wave;                            // GUARD: rows [0, rows_left) of the wave tile exist
     constexpr bool LNF = EPI == HMM_EPI_LN_BF16 || EPI == HMM_EPI_LN_GELU_BF16;
     if constexpr (EPI == HMM_EPI_BIAS_BF16 || EPI == HMM_EPI_BIAS_GELU_BF16 || LNF) {
         constexpr int RS = 144;
@@ -282,20 +283,23 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) c1v[ni] = *reinterpret_cast<const float4*>(aux.c1 + n_wave + ni * 16 + 4 * fq);
         }
+        float2 rsv[8];
+        if constexpr (LNF) {                                     // all eight row statistics first: one latency, not eight
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                int r = mi * 16 + fr;
+                if (GUARD) r = r < rows_left ? r : rows_left - 1;
+                rsv[mi] = aux.rs[(size_t)(m_wave + r) * aux.rs_stride];
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
-            float2 rs = make_float2(0.f, 0.f);
-            if constexpr (LNF) {
-                int m = m_wave + mi * 16 + fr;
-                m = m < M ? m : M - 1;
-                rs = aux.rs[(size_t)m * aux.rs_stride];
-            }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 f32x4 v = acc[mi][ni];
                 if constexpr (LNF) {
-                    v[0] = ln_fold(v[0], rs, c1v[ni].x, bv[ni].x); v[1] = ln_fold(v[1], rs, c1v[ni].y, bv[ni].y);
-                    v[2] = ln_fold(v[2], rs, c1v[ni].z, bv[ni].z); v[3] = ln_fold(v[3], rs, c1v[ni].w, bv[ni].w);
+                    v[0] = ln_fold(v[0], rsv[mi], c1v[ni].x, bv[ni].x); v[1] = ln_fold(v[1], rsv[mi], c1v[ni].y, bv[ni].y);
+                    v[2] = ln_fold(v[2], rsv[mi], c1v[ni].z, bv[ni].z); v[3] = ln_fold(v[3], rsv[mi], c1v[ni].w, bv[ni].w);
                 } else {
                     v[0] += bv[ni].x; v[1] += bv[ni].y; v[2] += bv[ni].z; v[3] += bv[ni].w;
                 }
@@ -308,36 +312,37 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        bf16_t* C = static_cast<bf16_t*>(Cout);
+        char* Cw = reinterpret_cast<char*>(static_cast<bf16_t*>(Cout) + (size_t)m_wave * N + n_wave);   // wave-uniform
         const int rsub = lane >> 3, chunk = lane & 7;
+        const unsigned lane_off = (unsigned)(rsub * N + chunk * 8) * 2u;
+        const unsigned row_step = (unsigned)N * 16u;            // 8 rows of bf16
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-            const int row = it * 8 + rsub;
-            const uint4 v = *reinterpret_cast<const uint4*>(slab + row * RS + chunk * 16);
-            const int m = m_wave + row;
-            if (m < M) {                                     // consumed once by the next kernel: non-temporal (+0.9 % on the forward)
-                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(C + (size_t)m * N + n_wave + chunk * 8));
-            }
+            const uint4 v = *reinterpret_cast<const uint4*>(slab + (it * 8 + rsub) * RS + chunk * 16);
+            if (!GUARD || it * 8 + rsub < rows_left)             // consumed once by the next kernel: non-temporal (+0.9 % on the forward)
+                __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(Cw + it * row_step + lane_off));
         }
     } else {
         constexpr int RS = 272;
         constexpr bool RESID = EPI == HMM_EPI_BIAS_RESID_F32 || EPI == HMM_EPI_BIAS_RESID_XB;
-        float* C = static_cast<float*>(Cout);
+        char* Cw = reinterpret_cast<char*>(static_cast<float*>(Cout) + (size_t)m_wave * N + n_wave);      // wave-uniform
         const int rsub = lane >> 4, chunk = lane & 15;
-        // Software-pipelined over four 32-row quarters: the residual rows of quarter q + 1 are requested before quarter q is
-        // read back, added and stored, so that a quarter never waits a full HBM latency, and only two quarters of residual
-        // (64 registers) are ever live beside the accumulators -- with both 64-row halves in flight (128 registers) the
-        // RESID_XB variant spilled 70 registers to scratch and took 1.6x as long (profiles/r3_resid_epilogue.json).
-        float4 xin[2][8];
-        auto load_resid = [&](int q) {                           // rows 32 q .. 32 q + 31 of the wave tile
+        const unsigned lane_off = (unsigned)(rsub * N + chunk * 4) * 4u;
+        const unsigned row_step = (unsigned)N * 16u;            // 4 rows of fp32
+        // Software-pipelined over 16-row groups: the residual rows of a group are requested one 32-row quarter before they
+        // are needed, into the registers the group of the previous quarter has just been added from -- a quarter never
+        // waits a full HBM latency and only 32 registers of residual are live beside the accumulators (with both 64-row
+        // halves in flight, 128 registers, the RESID_XB variant spilled 70 registers to scratch).
+        float4 xin[8];
+        auto load_resid = [&](int q, int g) {                    // rows 32 q + 16 g .. + 15 of the wave tile
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int m = m_wave + q * 32 + it * 4 + rsub;
-                xin[q & 1][it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < M) {                                     // streamed once: non-temporal (out-proj -2 % in the tower, -12 % alone)
-                    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(C + (size_t)m * N + n_wave + chunk * 4));
-                    xin[q & 1][it] = make_float4(t[0], t[1], t[2], t[3]);
+            for (int i = 0; i < 4; ++i) {
+                const int it = g * 4 + i, row = q * 32 + it * 4 + rsub;
+                xin[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!GUARD || row < rows_left) {                 // streamed once: non-temporal (out-proj -2 % in the tower, -12 % alone)
+                    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Cw + (q * 8 + it) * row_step + lane_off));
+                    xin[it] = make_float4(t[0], t[1], t[2], t[3]);
                 }
             }
         };
@@ -354,46 +359,86 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
             __builtin_amdgcn_wave_barrier();
         };
         auto drain = [&](int q) {                                // slab rows (+ residual) -> C, 256 B per 16 lanes
-            uint2 xb_even = make_uint2(0u, 0u);                   // RESID_XB: bf16 of the even iteration's row, kept for pairing
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = (q & 1) * 32 + it * 4 + rsub;     // row inside the 64-row slab
-                float4 v = *reinterpret_cast<const float4*>(slab + row * RS + chunk * 16);
-                const int m = m_wave + q * 32 + it * 4 + rsub;
+            for (int g = 0; g < 2; ++g) {                        // four rows at a time: reads batched, registers bounded
+                float4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    v[i] = *reinterpret_cast<const float4*>(slab + ((q & 1) * 32 + (g * 4 + i) * 4 + rsub) * RS + chunk * 16);
                 if constexpr (RESID) {
-                    v.x += xin[q & 1][it].x; v.y += xin[q & 1][it].y; v.z += xin[q & 1][it].z; v.w += xin[q & 1][it].w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float4 x = xin[g * 4 + i];
+                        v[i].x += x.x; v[i].y += x.y; v[i].z += x.z; v[i].w += x.w;
+                    }
+                    if (q < 3) load_resid(q + 1, g);             // the same group of the next quarter, into the freed registers
                 }
-                if (m < M) {
-                    if constexpr (RESID)
-                        __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(C + (size_t)m * N + n_wave + chunk * 4));
-                    else
-                        *reinterpret_cast<float4*>(C + (size_t)m * N + n_wave + chunk * 4) = v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int it = g * 4 + i;
+                    if (!GUARD || q * 32 + it * 4 + rsub < rows_left) {
+                        if constexpr (RESID)
+                            __builtin_nontemporal_store(f32x4{v[i].x, v[i].y, v[i].z, v[i].w},
+                                                        reinterpret_cast<f32x4*>(Cw + (q * 8 + it) * row_step + lane_off));
+                        else
+                            *reinterpret_cast<float4*>(Cw + (q * 8 + it) * row_step + lane_off) = v[i];
+                    }
                 }
                 if constexpr (EPI == HMM_EPI_BIAS_RESID_XB) {
-                    // The bf16 image of the new residual rows, 16 B per lane: a lane holds 4 columns (8 B) of row `it` and of
-                    // row `it + 1`; neighbours (chunk ^ 1) swap halves so that the even lane stores 8 columns of the first
-                    // row and the odd lane 8 columns of the second -- whole 128-B lines, half the store instructions.
-                    bf16x4 o4 = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
-                    {   // chunk statistics of this row's 64 columns (encoder_ops.h): leaf j = chunk, butterfly over the DPP row
-                        const float b0 = (float)o4[0], b1 = (float)o4[1], b2 = (float)o4[2], b3 = (float)o4[3];
-                        const float s = row16_sum(chunk_leaf_sum(b0, b1, b2, b3));
-                        const float q2 = row16_sum(chunk_leaf_sq(b0, b1, b2, b3, s * (1.0f / 64.0f)));
-                        if (aux.part != nullptr && chunk == 0 && m < M)
-                            aux.part[(size_t)m * (N >> 6) + (n_wave >> 6)] = make_float2(s, q2);
+                    // The bf16 image of the new residual rows and its chunk statistics (encoder_ops.h).  Statistics: leaf j =
+                    // chunk, butterfly over the DPP row; the four rows are reduced side by side (independent chains).
+                    uint2 xb[4];
+                    float s[4], sq[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        bf16x4 o4 = {(bf16_t)v[i].x, (bf16_t)v[i].y, (bf16_t)v[i].z, (bf16_t)v[i].w};
+                        xb[i] = __builtin_bit_cast(uint2, o4);
+                        v[i] = make_float4((float)o4[0], (float)o4[1], (float)o4[2], (float)o4[3]);
+                        s[i] = chunk_leaf_sum(v[i].x, v[i].y, v[i].z, v[i].w);
                     }
-                    const uint2 cur = __builtin_bit_cast(uint2, o4);
-                    if ((it & 1) == 0) {
-                        xb_even = cur;
-                    } else {
-                        const bool odd = chunk & 1;
-                        const uint2 send = odd ? xb_even : cur;   // what the neighbour stores: its row's other half
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[i] += dpp_mov_f32<0xB1>(s[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[i] += dpp_mov_f32<0x4E>(s[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[i] += dpp_mov_f32<0x141>(s[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[i] += dpp_mov_f32<0x140>(s[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sq[i] = chunk_leaf_sq(v[i].x, v[i].y, v[i].z, v[i].w, s[i] * (1.0f / 64.0f));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sq[i] += dpp_mov_f32<0xB1>(sq[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sq[i] += dpp_mov_f32<0x4E>(sq[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sq[i] += dpp_mov_f32<0x141>(sq[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sq[i] += dpp_mov_f32<0x140>(sq[i]);
+                    if (aux.part != nullptr && chunk == 0) {
+                        float2* pw = aux.part + (size_t)m_wave * (N >> 6) + (n_wave >> 6);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = q * 32 + (g * 4 + i) * 4 + rsub;
+                            if (!GUARD || row < rows_left) pw[(size_t)row * (N >> 6)] = make_float2(s[i], sq[i]);
+                        }
+                    }
+                    // xb, 16 B per lane: a lane holds 4 columns (8 B) of rows i and i + 1; neighbours (chunk ^ 1) swap halves so
+                    // that the even lane stores 8 columns of the first row and the odd lane 8 columns of the second -- whole
+                    // 128-B lines, half the store instructions.
+                    char* Xw = reinterpret_cast<char*>(aux.xb + (size_t)m_wave * N + n_wave);
+                    const bool odd = chunk & 1;
+                    const unsigned xoff = (unsigned)(rsub * N + (chunk & ~1) * 4) * 2u;
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        const uint2 send = odd ? xb[i] : xb[i + 1];          // what the neighbour stores: its row's other half
                         uint2 recv;
-                        recv.x = (unsigned)__shfl_xor((int)send.x, 1, 64);
-                        recv.y = (unsigned)__shfl_xor((int)send.y, 1, 64);
-                        const int m_st = odd ? m : m - 4;         // odd lanes store row `it`, even lanes row `it - 1`
-                        const uint4 qd = odd ? make_uint4(recv.x, recv.y, cur.x, cur.y) : make_uint4(xb_even.x, xb_even.y, recv.x, recv.y);
-                        if (m_st < M)
-                            *reinterpret_cast<uint4*>(aux.xb + (size_t)m_st * N + n_wave + (chunk & ~1) * 4) = qd;
+                        recv.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xF, 0xF, true);
+                        recv.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xF, 0xF, true);
+                        const int rbase = q * 32 + (g * 4 + i + (odd ? 1 : 0)) * 4;    // odd lanes store row i + 1, even lanes row i
+                        const uint4 qd = odd ? make_uint4(recv.x, recv.y, xb[i + 1].x, xb[i + 1].y)
+                                             : make_uint4(xb[i].x, xb[i].y, recv.x, recv.y);
+                        if (!GUARD || rbase + rsub < rows_left)
+                            *reinterpret_cast<uint4*>(Xw + (unsigned)rbase * (unsigned)N * 2u + xoff) = qd;
                     }
                 }
             }
@@ -402,18 +447,30 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         };
-        if constexpr (RESID) load_resid(0);
+        if constexpr (RESID) { load_resid(0, 0); load_resid(0, 1); }
         park(0);
-        if constexpr (RESID) load_resid(1);
         drain(0);
-        if constexpr (RESID) load_resid(2);
         drain(1);
         slab_free();
         park(1);
-        if constexpr (RESID) load_resid(3);
         drain(2);
         drain(3);
     }
+}
+
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const float* __restrict__ bias,
+                                                  void* __restrict__ Cout, int M, int N, int m_wave, int n_wave,
+                                                  char* slab, int lane, const GemmAux& aux) {
+    const int fq = lane >> 4;
+    float4 bv[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+        bv[ni] = bias ? *reinterpret_cast<const float4*>(bias + n_wave + ni * 16 + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m_wave + 128 <= M)                                       // wave-uniform
+        gemm_epilogue_lds_body<EPI, false>(acc, bv, Cout, M, N, m_wave, n_wave, slab, lane, aux);
+    else if (m_wave < M)
+        gemm_epilogue_lds_body<EPI, true>(acc, bv, Cout, M, N, m_wave, n_wave, slab, lane, aux);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -114,8 +114,8 @@ class HipTower:
         _lib.check(self._lib.hmm_encoder_set_fused_attention(self._h, int(bool(on))), "hmm_encoder_set_fused_attention")
 
     def set_folded_layernorm(self, on: bool):
-        """Vision tower: LayerNorm folded into the neighbouring GEMMs (default) or run as its own kernel; results agree
-        within the bf16 noise, not bitwise (include/hippomm_hip.h)."""
+        """Vision tower: LayerNorm folded into the neighbouring GEMMs (opt-in) or run as its own kernel (default: it is
+        the faster of the two); results agree within the bf16 noise, not bitwise (include/hippomm_hip.h)."""
         _lib.check(self._lib.hmm_encoder_set_folded_layernorm(self._h, int(bool(on))), "hmm_encoder_set_folded_layernorm")
 
     def set_streams(self, n: int):

@@ -163,12 +163,13 @@ double hmm_encoder_flops_executed(const hmm_encoder* enc, int batch);
  * by the handle (forked from / joined to the caller's stream with events).  n_streams = 1: one chain on the caller's
  * stream only.  Embeddings are bitwise identical either way (tests/test_gpu_encoder_batch.py). */
 int  hmm_encoder_set_streams(hmm_encoder* enc, int n_streams);
-/* Vision tower: on (default) = in_proj and the attention core of a block run as ONE kernel per (image, head) and the
- * packed qkv matrix never goes through HBM; off = a QKV GEMM followed by the attention kernel.  Embeddings are bitwise
- * identical either way.  No effect on the audio / text towers (their head shapes keep the two-kernel path). */
+/* Vision and audio towers: on (default) = in_proj and the attention core of a block run as ONE kernel per (sample, head)
+ * and the packed qkv matrix never goes through HBM; off = a QKV GEMM followed by the attention kernel.  Embeddings are
+ * bitwise identical either way.  No effect on the text tower (77 tokens would fill 30 % of the kernel's 256-row tile). */
 int  hmm_encoder_set_fused_attention(hmm_encoder* enc, int on);
-/* Vision tower, every block but the last: on (default once all parameters are loaded) = no LayerNorm pass over the residual
- * stream.  The residual GEMMs also emit xb = bf16(x); a statistics kernel takes (rstd, rstd * mean) of the xb rows; in_proj
+/* Vision tower, every block but the last: on (possible once all parameters are loaded; OFF by default -- measured slower than
+ * the LayerNorm kernel on MI355X) = no LayerNorm pass over the residual stream.  The residual GEMMs also emit
+ * xb = bf16(x) and the per-64-column chunk statistics of its rows, a small kernel combines them into (rstd, rstd * mean); in_proj
  * and fc1 run on xb with weights bf16(gamma (.) W) and finish the normalisation in their epilogue:
  *   LN(xb) W^T + b = rstd * (xb W'^T) - rstd * mean * rowsum(W') + (W beta + b).
  * off = the LayerNorm kernel (fp32 statistics of x, result rounded to bf16) + plain GEMMs, as the audio / text towers run.
