@@ -678,6 +678,9 @@ def main():
             except Exception as exc:                           # noqa: BLE001
                 sharded_scan = {"error": f"{type(exc).__name__}: {exc}"}
 
+    if rank == 0 and os.environ.get("HMM_BENCH_DUMP"):         # debugging aid: the gathered embedding matrix of the last step
+        import numpy as np
+        np.save(os.environ["HMM_BENCH_DUMP"], feats.cpu().numpy())
     if rank == 0:
         value = n_total * args.steps / elapsed
         ms_step = elapsed / args.steps * 1e3

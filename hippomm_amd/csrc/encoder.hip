@@ -24,6 +24,7 @@
 
 namespace hmm {
 
+HMM_TUNABLE(int, g_enc_split_num, 128)   // frames of 256 that go to the first of the two chains
 HMM_TUNABLE(int, g_enc_fold_default, 0)  // 1 = a vision tower starts with LayerNorm folded (hmm_encoder_set_folded_layernorm switches it)
 
 enum PackKind { PACK_F32, PACK_BF16, PACK_FOLD_CONV3D };
@@ -360,7 +361,8 @@ namespace hmm {
 // (every frame's rows go through the same kernels with the same K order).
 static int split_point(const hmm_encoder* e, int batch) {
     if (e->streams < 2 || batch * e->clips < 64) return 0;
-    return batch / 2;
+    const int b0 = (int)((long)batch * g_enc_split_num / 256);     // probe build: uneven halves (tile-round quantisation A/B)
+    return b0 < 1 ? 1 : (b0 >= batch ? batch - 1 : b0);
 }
 }  // namespace hmm
 

@@ -646,10 +646,14 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         const long tiles = (long)tiles_m * tiles_n;
         // few 256x256 tiles (cls-only last block, head): 128x128 tiles put 4x more CUs to work
         if (tiles < 128) return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
+        // peel p <= 2 row tiles when that leaves the main launch with a last round that is full or nearly full (>= 240 of 256
+        // CUs) instead of a nearly empty one
         int peel = 0;
         if (tiles > 256 && tiles % 256 != 0 && tiles % 256 <= 64)
-            for (int p = 1; p <= 2 && !peel; ++p)
-                if (((long)(tiles_m - p) * tiles_n) % 256 == 0) peel = p;
+            for (int p = 1; p <= 2 && !peel; ++p) {
+                const long r = ((long)(tiles_m - p) * tiles_n) % 256;
+                if (r == 0 || r >= 240) peel = p;
+            }
         if (!peel) return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, aux, st);
         const int m_main = (tiles_m - peel) * 256;
         int rc = launch_gemm_pp_epi(A, W, bias, C, m_main, N, K, epi, aux, st);

@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" --
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/lds" -- python3 "$REPO/tools/pmc_workload.py" > "$OUT/lds.log" 2>&1
 cd "$REPO"
 mkdir -p "gpurun_out/pmc_${TAG}_summary"
-python3 tools/pmc_summarize.py "$OUT" "gpurun_out/pmc_${TAG}_summary/r2"
+python3 tools/pmc_summarize.py "$OUT" "gpurun_out/pmc_${TAG}_summary/${PREFIX:-r3}"
 ls "gpurun_out/pmc_${TAG}_summary"
 # keep only what the summariser read (the merge back is capped at 64 MiB)
 find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete
