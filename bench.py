@@ -103,20 +103,26 @@ def launch_ranks(n: int, argv) -> int:
 # synthetic input and the step (also driven on CPU / gloo by tests/test_cpu_bench_step.py)
 # ------------------------------------------------------------------------------------------------
 def synthetic_frames(lo: int, hi: int, device, amp: float = 1.5, sigma: float = 0.3) -> torch.Tensor:
-    """Frames lo..hi-1 of the synthetic video, identical whatever the sharding: scene s = frame // SCENE_LEN is a
-    low-frequency pattern (4x4 random field, bilinear to 224x224, seeded by s), each frame adds pixel noise seeded
-    by its own index.  Stands for CLIP-normalised pixels, i.e. post-load_data."""
-    out = torch.empty(hi - lo, 3, 224, 224, dtype=torch.float32, device=device)
+    """Frames lo..hi-1 of the synthetic video, BIT-identical whatever the sharding and whatever process makes them: scene
+    s = frame // SCENE_LEN is a low-frequency pattern (4x4 random field seeded by s, bilinear to 224x224), each frame adds
+    pixel noise seeded by its own index.  Everything is drawn and computed on `device` (Philox streams, element-wise
+    kernels): the host-side version of this function gave fp32 pixels that differed in the last bit with the number of
+    OpenMP threads (torch.distributed.run sets OMP_NUM_THREADS=1), enough to move 96 % of the bf16 embeddings of a
+    multi-rank run away from the one-process run.  Stands for CLIP-normalised pixels, i.e. post-load_data."""
+    dev = torch.device(device)
+    out = torch.empty(hi - lo, 3, 224, 224, dtype=torch.float32, device=dev)
+    g = torch.Generator(device=dev)
     scene, scene_id = None, -1
     for i in range(lo, hi):
         s = i // SCENE_LEN
         if s != scene_id:
-            g = torch.Generator().manual_seed(1000 + s)
-            base = torch.randn(1, 3, 4, 4, generator=g) * amp
+            g.manual_seed(1000 + s)
+            base = torch.randn(1, 3, 4, 4, generator=g, device=dev) * amp
             scene = torch.nn.functional.interpolate(base, size=(224, 224), mode="bilinear", align_corners=False)[0]
             scene_id = s
-        g = torch.Generator().manual_seed(7_000_000 + i)
-        out[i - lo] = (scene + sigma * torch.randn(3, 224, 224, generator=g)).to(device)
+        g.manual_seed(7_000_000 + i)
+        noise = torch.randn(3, 224, 224, generator=g, device=dev)
+        out[i - lo] = scene + sigma * noise
     return out
 
 

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void fold_ln_weights_kernel(const float* __res
     if (tid == 0) { c1[n] = (float)red[0][0]; c2[n] = (float)(red[1][0] + (double)bias[n]); }
 }
 
-HMM_TUNABLE(int, g_ln_nt_loads, 0)       // probe build: 1 = non-temporal loads of the fp32 residual stream in LayerNorm (A/B)
+HMM_TUNABLE(int, g_ln_nt_loads, 1)       // non-temporal loads of the fp32 residual stream in LayerNorm (read once; keeps the bf16 output cache-resident for its consumer: forward -0.9 %, profiles/r3_forward_ab.json); probe build: A/B
 
 int launch_layernorm_bf16(const float* x, size_t in_stride, const float* g, const float* b, bf16_t* y,
                           int rows, int D, float eps, hipStream_t st) {

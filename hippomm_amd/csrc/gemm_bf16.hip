@@ -478,14 +478,24 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
 // in_proj + attention kernel).  Tiles are walked in plain strips (whole row tiles, XCD-contiguous); ablations, tile-walk and
 // pipeline variants that were measured and rejected are recorded in DESIGN.md section 4.3 / 4.5, not kept in the code.
 // ------------------------------------------------------------------------------------------------
+// Tile walk inside the XCD-contiguous order: 0 = strips (a row tile's column tiles are consecutive); (R << 8) | C = blocks of
+// R row tiles x C column tiles.  Strips re-stream the whole weight matrix from the Infinity Cache once per row tile (fc1:
+// 2.35 GB through the fabric per launch for 0.18 GB of operands); 6 x 5 blocks make that 1.65 GB and the fc1 GEMM 3 % faster
+// (0.5 % on the forward), and do nothing for the K = 5120 and N = 1280 shapes (profiles/r3_walk_evidence.json,
+// r3_walk_fetch.json).  -1 (product default) = 6 x 5 where the column tiles split into whole groups of five and there are
+// enough row tiles, strips otherwise.  Which workgroup computes a tile does not change the tile: same bits.
+HMM_TUNABLE(int, g_gemm_walk, -1)
+static int pick_walk(int tiles_m, int tiles_n) {
+    if (g_gemm_walk >= 0) return g_gemm_walk;
+    return (tiles_n >= 10 && tiles_n % 5 == 0 && tiles_m >= 48) ? ((6 << 8) | 5) : 0;
+}
 #ifdef HMM_PROBE
 // in-kernel stamps (s_memrealtime, 100 MHz): per workgroup {start, -, main loop done, stores retired, XCC id, HW id};
 // written to a buffer of their own that nothing else reads
-HMM_TUNABLE(int, g_gemm_walk, 0)   // 0 = strips; (R << 8) | C = blocks of R row tiles x C column tiles inside the XCD-contiguous order
 unsigned long long* g_gemm_stamps = nullptr;
 extern "C" void hmm_probe_set_gemm_stamps(unsigned long long* p) { g_gemm_stamps = p; }
-#define HMM_PROBE_ARG , unsigned long long* stamps, int walk
-#define HMM_PROBE_VAL , g_gemm_stamps, g_gemm_walk
+#define HMM_PROBE_ARG , unsigned long long* stamps
+#define HMM_PROBE_VAL , g_gemm_stamps
 #define HMM_STAMP(slot)                                                                              \
     if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();
 #else
@@ -499,7 +509,7 @@ HMM_TUNABLE(int, g_gemm_skip_tail, 0)   // probe build: 1 = do not launch the pe
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    void* __restrict__ Cout, int M, int N, int K, int tiles_n, GemmAux aux HMM_PROBE_ARG) {
+    void* __restrict__ Cout, int M, int N, int K, int tiles_n, int walk, GemmAux aux HMM_PROBE_ARG) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -510,7 +520,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     int m0 = (swz / tiles_n) * 256, n0 = (swz % tiles_n) * 256;
-#ifdef HMM_PROBE
     if (walk) {
         const int R = walk >> 8, C = walk & 255, tiles_m = nb / tiles_n;
         const int rg = swz / (R * tiles_n), rem = swz - rg * R * tiles_n;
@@ -520,7 +529,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
         m0 = (rg * R + rem2 / wc) * 256;
         n0 = (cg * C + rem2 % wc) * 256;
     }
-#endif
     HMM_STAMP(0)
 #ifdef HMM_PROBE
     if (stamps && threadIdx.x == 0) stamps[(size_t)bid * 8 + 6] = __builtin_amdgcn_s_memtime();
@@ -575,7 +583,7 @@ static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
     const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
     auto kern = gemm_bf16_pp_kernel<EPI>;
     HMM_ENSURE_DYN_LDS(kern, LDS);
-    kern<<<tiles_m * tiles_n, 512, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n, aux HMM_PROBE_VAL);
+    kern<<<tiles_m * tiles_n, 512, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n, pick_walk(tiles_m, tiles_n), aux HMM_PROBE_VAL);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }

@@ -153,6 +153,27 @@ def test_gemm_cfg2_rows_peeled_tail():
     torch.testing.assert_close(x[rows], x0[rows] + want, rtol=2e-5, atol=3e-4)
 
 
+@pytest.mark.parametrize("M", [256 * 50 + 31, 256 * 61])
+def test_gemm_block_walk_covers_every_tile(M):
+    """N = 5120 with >= 48 row tiles takes the 6 x 5 block walk (gemm_bf16.hip pick_walk): 50 / 61 row tiles leave a last
+    row group of 2 / 1 tiles and M % 256 = 31 a ragged last tile.  Every output element must be written (the buffer starts
+    as NaN) and equal the 128 x 128 tile kernel's, which walks plain rows."""
+    L, lib = _lib()
+    N, K = 5120, 256
+    g = torch.Generator(device="cuda").manual_seed(M)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    got = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), got.data_ptr(), M, N, K, EPI_BIAS_BF16, 3,
+                                      L.stream_ptr()), "gemm pp")
+    ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), ref.data_ptr(), M, N, K, EPI_BIAS_BF16, 0,
+                                      L.stream_ptr()), "gemm 128")
+    assert torch.isnan(got[M].float()).all() and not torch.isnan(got[:M].float()).any()
+    assert torch.equal(got[:M], ref)
+
+
 def test_gemm_identity_asymmetric():
     """A = I against an asymmetric W catches a transposed / permuted accumulator mapping exactly."""
     L, lib = _lib()

@@ -15,13 +15,13 @@ from hippomm_amd.encoder import HipTower, synthetic_state_dict
 tower = HipTower("vision", synthetic_state_dict(("vision",), seed=1234))
 torch.cuda.empty_cache()
 KNOBS = ("g_enc_fold_stats", "g_gemm_skip_tail", "g_ln_nt_loads", "g_gemm_walk")
-BASE = dict(fold=0, g_enc_fold_stats=1, g_gemm_skip_tail=0, g_ln_nt_loads=0, g_gemm_walk=0)
+BASE = dict(fold=0, g_enc_fold_stats=1, g_gemm_skip_tail=0, g_ln_nt_loads=1, g_gemm_walk=-1)      # the product's defaults
 W84, W65 = (8 << 8) | 4, (6 << 8) | 5
-configs_big = [("ln_kernel", {}), ("ln_kernel_ntload", dict(g_ln_nt_loads=1)), ("ln_kernel_walk8x4", dict(g_gemm_walk=W84)),
-               ("ln_kernel_walk6x5", dict(g_gemm_walk=W65)), ("ln_kernel_notail", dict(g_gemm_skip_tail=1)),
-               ("fold_epi", dict(fold=1)), ("fold_pass", dict(fold=1, g_enc_fold_stats=0)),
-               ("fold_epi_walk8x4", dict(fold=1, g_gemm_walk=W84)), ("fold_epi_walk6x5", dict(fold=1, g_gemm_walk=W65))]
-configs_small = [("ln_kernel", {}), ("fold_epi", dict(fold=1)), ("fold_pass", dict(fold=1, g_enc_fold_stats=0))]
+configs_big = [("product", {}), ("ln_plain_loads", dict(g_ln_nt_loads=0)), ("walk_strips", dict(g_gemm_walk=0)),
+               ("walk_8x4_all", dict(g_gemm_walk=W84)), ("walk_6x5_all", dict(g_gemm_walk=W65)),
+               ("round2_like", dict(g_ln_nt_loads=0, g_gemm_walk=0)),
+               ("fold_epi", dict(fold=1)), ("fold_pass", dict(fold=1, g_enc_fold_stats=0))]
+configs_small = [("product", {}), ("fold_epi", dict(fold=1))]
 res = {}
 for B in (256, 32, 128):
     configs = configs_big if B == 256 else configs_small
@@ -40,6 +40,6 @@ for B in (256, 32, 128):
         print(f"B={B} {name:20s} median {res[f'B{B}_{name}']['ms_median']:8.3f} ms  min {t[0]:8.3f}  {res[f'B{B}_{name}']['img_per_s']} img/s", flush=True)
 for k in KNOBS:
     setter(lib, k)(BASE[k])
-tower.set_folded_layernorm(True)
+tower.set_folded_layernorm(False)
 if len(sys.argv) > 1:
     json.dump(res, open(sys.argv[1], "w"), indent=1)
