@@ -18,6 +18,7 @@ c_ptr = C.c_void_p
 _SIGNATURES = {
     "hmm_abi_version": (C.c_int, []),
     "hmm_last_error": (C.c_char_p, []),
+    "hmm_device_supported": (C.c_int, []),
     "hmm_cosine_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "hmm_cosine_topk": (C.c_int, [c_ptr, C.c_int64, C.c_int, c_ptr, C.c_int, c_ptr, c_ptr, c_ptr,
                                   c_ptr, C.c_size_t, c_ptr]),
@@ -101,11 +102,18 @@ def check(status: int, what: str):
         raise HippoMMHipError(f"{what} failed (status {status}): {msg}")
 
 
+_checked_devices = set()
+
+
 def require_gpu():
     import torch
     if not torch.cuda.is_available():
         raise HippoMMHipError("hippomm_amd needs a ROCm GPU (MI355X / gfx950); no CPU fallback exists")
-    return torch.device("cuda", torch.cuda.current_device())
+    dev = torch.cuda.current_device()
+    if dev not in _checked_devices:                      # once per device: gfx950 with 256 CUs, or refuse loudly
+        check(load().hmm_device_supported(), "hmm_device_supported")
+        _checked_devices.add(dev)
+    return torch.device("cuda", dev)
 
 
 def stream_ptr():

@@ -24,6 +24,7 @@
 
 namespace hmm {
 
+HMM_TUNABLE(int, g_enc_side_priority, 0) // probe build: HIP priority of the second chain's stream (0 normal, 1 low, -1 high), read at create
 HMM_TUNABLE(int, g_enc_split_num, 128)   // frames of 256 that go to the first of the two chains
 HMM_TUNABLE(int, g_enc_fold_default, 0)  // 1 = a vision tower starts with LayerNorm folded (hmm_encoder_set_folded_layernorm switches it)
 
@@ -257,7 +258,8 @@ extern "C" int hmm_encoder_create(hmm_encoder** out, int tower, int depth) {
     if (err == hipSuccess && e->fold_stage_bytes) err = hipMalloc(reinterpret_cast<void**>(&e->fold_stage), e->fold_stage_bytes);
     // the side stream and its fork/join events belong to the handle's device and exist before the first forward,
     // so that hmm_encoder_forward creates nothing (graph capture) and never lands them on another current device
-    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = g_enc_side_priority == 0 ? hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking)
+                                                          : hipStreamCreateWithPriority(&e->side_stream, hipStreamNonBlocking, g_enc_side_priority);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
     for (int c = 0; c < 2 && err == hipSuccess; ++c) {

@@ -44,6 +44,10 @@ typedef void* hmm_stream_t;   /* hipStream_t */
 
 int         hmm_abi_version(void);
 const char* hmm_last_error(void);
+/* HMM_OK when the current HIP device is what this library is built for (gfx950 with 256 compute units: the launch
+ * geometries and the code objects assume it); HMM_E_STATE with a message otherwise.  The Python package calls it once per
+ * device before the first kernel. */
+int         hmm_device_supported(void);
 
 /* ------------------------------------------------------------------------------------------
  * feature_search scan.  Replaces top_k_cosine_similarity(a, b, k)
