@@ -53,6 +53,20 @@ def scan_case(name: str):
         if name.endswith("f64"):
             store = store.astype(np.float64)
         return query, store, (32 if "k32" in name else 5)
+    if name in ("n32_k5_textquery", "n150_k5_textquery", "n450_k5_textquery", "n3600_k5_textquery_f64"):
+        # the retrieval call as QARecallSystem makes it (hippocampal_memory.py:2173-2176 -> :3153): the query is a TEXT embedding
+        # (unit vector x exp(log_logit_scale) = 1 / 0.07), the store one event's unit-norm vision rows (32 = a frame buffer,
+        # 3600 = an hour at 1 fps), k = 5; weakly related rows, i.e. the small similarity gaps of a real cross-modal query
+        n = int(name.split("_")[0][1:])
+        rng = np.random.default_rng(4000 + n)
+        store = rng.standard_normal((n, D)).astype(np.float32)
+        store /= np.linalg.norm(store, axis=1, keepdims=True)
+        target = store[(2 * n) // 3] + store[n // 5]
+        query = target + 2.0 * rng.standard_normal(D).astype(np.float32) * np.linalg.norm(target) / 32
+        query = (query / np.linalg.norm(query) * np.float32(1.0 / 0.07)).astype(np.float32)
+        if name.endswith("f64"):
+            store = store.astype(np.float64)
+        return query, store, 5
     if name == "k_gt_n":
         rng = np.random.default_rng(5)
         return rng.standard_normal(D, dtype=np.float32), rng.standard_normal((7, D), dtype=np.float32), 32
@@ -76,7 +90,8 @@ def scan_case(name: str):
 
 SCAN_CASES = ["n4096_k5", "n4096_k32", "n4096_k32_f64store", "n300_k5_unitrows",
               "k_gt_n", "store_1d", "duplicate_rows", "zero_row",
-              "n1000_k5_unitrows_audio20", "n2500_k5_unitrows", "n64_k5_event", "n777_k32_unitrows_f64"]
+              "n1000_k5_unitrows_audio20", "n2500_k5_unitrows", "n64_k5_event", "n777_k32_unitrows_f64",
+              "n32_k5_textquery", "n150_k5_textquery", "n450_k5_textquery", "n3600_k5_textquery_f64"]
 
 
 # ------------------------------------------------------------- select (a7)
