@@ -48,8 +48,8 @@ struct AttnCfg {
     // different bank pairs instead of 2 (rows are 48 dwords apart: 8-way conflicts, 12 % of that kernel's LDS cycles).
     static __device__ __forceinline__ int v_swz(int row) { return HMM_V_SWIZZLE ? (row >> 1) & 7 : 0; }
     static __device__ __forceinline__ int v_chunk(int row, int chunk8) { return (chunk8 & ~7) | ((chunk8 & 7) ^ v_swz(row)); }
-    static __device__ __forceinline__ int v_byte(int row, int byte_col) {     // byte offset of (row, byte_col) in the image:
-        return row * VROW + (byte_col ^ (v_swz(row) << 3));                     // the XOR only touches chunk bits 3..5
+    static __device__ __forceinline__ int v_byte(int row, int byte_col) {     // byte offset of (row, byte_col) in the image
+        return row * VROW + v_chunk(row, byte_col >> 3) * 8 + (byte_col & 7);
     }
 };
 

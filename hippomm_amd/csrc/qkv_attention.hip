@@ -124,7 +124,6 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
                 if constexpr (LNF) cv = *reinterpret_cast<const float4*>(c1 + part * kD + h * kDH + d);
                 char* img = part == 0 ? q_lds : (part == 1 ? k_lds : v_lds);
                 const int stride = part == 0 ? P::QRow : (part == 1 ? Cfg::KROW : Cfg::VROW);
-                const int vmask = part == 2 ? 0x38 : 0;                  // V rows: chunk swizzle (attention_core.h v_byte)
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) {
                     const int tok = G::ROW0 + wm * 128 + mi * 16 + fr;
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
                     else
                         o4 = bf16x4{(bf16_t)(v[0] + bv.x), (bf16_t)(v[1] + bv.y), (bf16_t)(v[2] + bv.z), (bf16_t)(v[3] + bv.w)};
                     if (G::ROW0 + 255 < kT || tok < kT)                  // tile rows past the last token are dropped
-                        *reinterpret_cast<bf16x4*>(img + tok * stride + ((d * 2) ^ ((Cfg::v_swz(tok) << 3) & vmask))) = o4;
+                        *reinterpret_cast<bf16x4*>(img + (part == 2 ? Cfg::v_byte(tok, d * 2) : tok * stride + d * 2)) = o4;
                 }
             }
         }
