@@ -79,29 +79,21 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
         for (int idx = T * CPR + tid; idx < NCHUNK; idx += NT) {
             const int row = idx / CPR, c = idx - row * CPR;
             *reinterpret_cast<uint4*>(k_lds + row * C::KROW + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(v_lds + row * C::VROW + c * 16) = make_uint4(0u, 0u, 0u, 0u);
         }
-        // V rows are zeroed over their whole stride: the chunk swizzle moves valid columns of a half-used 64-byte window
-        // (dh 80) into its other half, and a masked key must contribute 0 x 0, never 0 x garbage
-        constexpr int VCH = C::VROW / 16;
-        for (int idx = T * VCH + tid; idx < C::NKEY * VCH; idx += NT)
-            *reinterpret_cast<uint4*>(v_lds + idx * 16) = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
             const int idx = tid + i * NT;
             const int row = idx / CPR, c = idx - row * CPR;
             if (row < T) {
                 *reinterpret_cast<uint4*>(k_lds + row * C::KROW + c * 16) = kv[i];
-                // V image swizzle (AttnCfg::v_chunk) at 16-B granularity: the chunk pair moves by (s >> 1), its halves swap if s is odd
-                const int s = C::v_swz(row);
-                const uint4 v = vv[i];
-                *reinterpret_cast<uint4*>(v_lds + row * C::VROW + ((c & ~3) | ((c & 3) ^ (s >> 1))) * 16) =
-                    (s & 1) ? make_uint4(v.z, v.w, v.x, v.y) : v;
+                *reinterpret_cast<uint4*>(v_lds + row * C::VROW + c * 16) = vv[i];
             }
         }
         __syncthreads();
         if (bias_k != nullptr && tid < DH) {             // the add_bias_kv position: row T
             *reinterpret_cast<bf16_t*>(k_lds + T * C::KROW + tid * 2) = (bf16_t)bias_k[h * DH + tid];
-            *reinterpret_cast<bf16_t*>(v_lds + C::v_byte(T, tid * 2)) = (bf16_t)bias_v[h * DH + tid];
+            *reinterpret_cast<bf16_t*>(v_lds + T * C::VROW + tid * 2) = (bf16_t)bias_v[h * DH + tid];
         }
     }
     __syncthreads();

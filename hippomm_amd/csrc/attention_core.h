@@ -4,8 +4,7 @@
 //
 // One workgroup (8 waves, two per SIMD) per (sample, head).  K and V are ROW-major in LDS: K rows padded to an odd
 // multiple of 16 B (conflict-free ds_read_b128 of the A-operand), V rows at a 192-B stride (the four rows a
-// ds_read_b64_tr_b16 block touches fall in disjoint bank windows) with their 8-byte chunks XOR-permuted per row pair
-// (AttnCfg::v_chunk: conflict-free column-chunk writes from the fused kernel).  Each wave owns 32-query tiles.
+// ds_read_b64_tr_b16 block touches fall in disjoint bank windows).  Each wave owns 32-query tiles.
 //
 // The score tile is computed TRANSPOSED, S^T = K Q^T (v_mfma_f32_32x32x16_bf16, K as the A-operand),
 // so a lane holds one query column with its keys in registers: max / sum are register-local plus
@@ -18,10 +17,6 @@
 // fp32 scores, statistics and output accumulation; P and the output are rounded to bf16 once.
 #pragma once
 #include "hmm_common.h"
-
-#ifndef HMM_V_SWIZZLE
-#define HMM_V_SWIZZLE 1            // 0: plain V rows (A/B builds only)
-#endif
 
 namespace hmm {
 
@@ -42,15 +37,6 @@ struct AttnCfg {
     static constexpr int CH = 3;                    // key tiles per online-softmax chunk
     static constexpr int NCH = (NKT + CH - 1) / CH;
     static_assert(DT * 64 <= VROW, "V row must cover every d tile a tr-read touches");
-    // V image: inside every 64-byte window of a row the eight 8-byte chunks are XOR-permuted by (row >> 1) & 7.  The
-    // transposing reads do not care (a 32-lane group reads whole windows of four rows: the same banks, permuted), but a
-    // writer that holds 16 consecutive ROWS of one column chunk -- the fused kernel's accumulator layout -- then hits 16
-    // different bank pairs instead of 2 (rows are 48 dwords apart: 8-way conflicts, 12 % of that kernel's LDS cycles).
-    static __device__ __forceinline__ int v_swz(int row) { return HMM_V_SWIZZLE ? (row >> 1) & 7 : 0; }
-    static __device__ __forceinline__ int v_chunk(int row, int chunk8) { return (chunk8 & ~7) | ((chunk8 & 7) ^ v_swz(row)); }
-    static __device__ __forceinline__ int v_byte(int row, int byte_col) {     // byte offset of (row, byte_col) in the image
-        return row * VROW + v_chunk(row, byte_col >> 3) * 8 + (byte_col & 7);
-    }
 };
 
 constexpr int kAttnWaves = 8;
@@ -74,11 +60,7 @@ __device__ __forceinline__ void attention_core(const char* k_lds, const char* v_
     // tr-read: 16-lane group g = lane>>4 reads a 4-key x 16-d block; lane (4q+p) of the group supplies
     // row q, columns 4p..4p+3, and receives column (lane&15) of the 4 rows.
     const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    // rows 4 (g >> 1) + q4 (v0) and + 8 (v1) of a 16-key step, chunk 4 (g & 1) + p4 of the d tile's window, swizzled as the
-    // image is (the key-step base is a multiple of 16 rows and leaves (row >> 1) & 7 alone; + 8 rows flips its bit 2)
-    const int v_cw = 4 * (g & 1) + p4, v_r0 = 4 * (g >> 1) + q4;
-    const char* v_base = v_lds + v_r0 * C::VROW + ((v_cw ^ C::v_swz(v_r0)) * 8);
-    const char* v_base8 = v_lds + (v_r0 + 8) * C::VROW + ((v_cw ^ C::v_swz(v_r0 + 8)) * 8);
+    const char* v_base = v_lds + (4 * (g >> 1) + q4) * C::VROW + (16 * (g & 1) + 4 * p4) * 2;
 
     // 257 = 8*32 + 1: a ninth query tile with ONE valid row would make wave 0 run two tiles back to
     // back (the critical path of the workgroup).  When the tile past the 8 main ones holds exactly one
@@ -183,9 +165,9 @@ __device__ __forceinline__ void attention_core(const char* k_lds, const char* v_
                         for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[i][8 * st + j];
 #pragma unroll
                         for (int dt = 0; dt < C::DT; ++dt) {
-                            const int voff = (kt * 32 + 16 * st) * C::VROW + dt * 64;
-                            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(v_base + voff));
-                            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(v_base8 + voff));
+                            const char* vp = v_base + (kt * 32 + 16 * st) * C::VROW + dt * 64;
+                            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp));
+                            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp + 8 * C::VROW));
                             const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                             o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
                         }
@@ -257,9 +239,9 @@ __device__ __forceinline__ void attention_core(const char* k_lds, const char* v_
                 for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)sx[8 * st + j];
 #pragma unroll
                 for (int dt = 0; dt < C::DT; ++dt) {
-                    const int voff = (kt * 32 + 16 * st) * C::VROW + dt * 64;
-                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(v_base + voff));
-                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(v_base8 + voff));
+                    const char* vp = v_base + (kt * 32 + 16 * st) * C::VROW + dt * 64;
+                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp));
+                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp + 8 * C::VROW));
                     const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     ox[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ox[dt], 0, 0, 0);
                 }

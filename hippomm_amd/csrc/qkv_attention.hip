@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
                     else
                         o4 = bf16x4{(bf16_t)(v[0] + bv.x), (bf16_t)(v[1] + bv.y), (bf16_t)(v[2] + bv.z), (bf16_t)(v[3] + bv.w)};
                     if (G::ROW0 + 255 < kT || tok < kT)                  // tile rows past the last token are dropped
-                        *reinterpret_cast<bf16x4*>(img + (part == 2 ? Cfg::v_byte(tok, d * 2) : tok * stride + d * 2)) = o4;
+                        *reinterpret_cast<bf16x4*>(img + tok * stride + d * 2) = o4;
                 }
             }
         }
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
         if constexpr (G::BIAS_KV) {                                      // the add_bias_kv position: key row T
             if (tid < kDH) {
                 *reinterpret_cast<bf16_t*>(k_lds + kT * Cfg::KROW + tid * 2) = (bf16_t)bias_k[h * kDH + tid];
-                *reinterpret_cast<bf16_t*>(v_lds + Cfg::v_byte(kT, tid * 2)) = (bf16_t)bias_v[h * kDH + tid];
+                *reinterpret_cast<bf16_t*>(v_lds + kT * Cfg::VROW + tid * 2) = (bf16_t)bias_v[h * kDH + tid];
             }
         }
         // key rows LK .. NKEY-1: zeros
@@ -161,10 +161,8 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
         for (int idx = LK * CPR + tid; idx < Cfg::NKEY * CPR; idx += 512) {
             const int row = idx / CPR, c = idx - row * CPR;
             *reinterpret_cast<uint4*>(k_lds + row * Cfg::KROW + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(v_lds + row * Cfg::VROW + c * 16) = make_uint4(0u, 0u, 0u, 0u);
         }
-        constexpr int VCH = Cfg::VROW / 16;                             // V rows over their whole stride (chunk swizzle, attention_core.h)
-        for (int idx = LK * VCH + tid; idx < Cfg::NKEY * VCH; idx += 512)
-            *reinterpret_cast<uint4*>(v_lds + idx * 16) = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
 
