@@ -1,5 +1,5 @@
-"""BASELINE cfg 3 (128 frame + audio pairs) with the audio tower's fused in_proj + attention kernel on / off, and the audio
-tower alone; interleaved rounds in one process.  usage: joint_probe.py"""
+"""BASELINE cfg 3 (128 frame + audio pairs): vision then audio on one stream (as round 2 timed it) against the two towers
+issued on two streams (each still forks its own second chain), interleaved rounds in one process.  usage: joint_probe.py"""
 from probe_common import ROOT, event_ms  # noqa: F401
 import torch
 from hippomm_amd.encoder import HipTower, synthetic_state_dict
@@ -11,14 +11,30 @@ del sd
 frames = torch.randn(pairs, 3, 224, 224, device="cuda")
 mels = torch.randn(pairs, 3, 1, 128, 204, device="cuda")
 ev, ea = torch.empty(pairs, 1024, device="cuda"), torch.empty(pairs, 1024, device="cuda")
-def both():
+side = torch.cuda.Stream()
+vis.forward_into(frames, ev); aud.forward_into(mels, ea); torch.cuda.synchronize()
+ref_v, ref_a = ev.clone(), ea.clone()
+
+
+def serial():
     vis.forward_into(frames, ev); aud.forward_into(mels, ea)
-res = {}
-for rnd in range(3):
-    for fused in (1, 0):
-        aud.set_fused_attention(bool(fused))
-        res.setdefault(("joint", fused), []).append(event_ms(both, 5, warmup=2))
-        res.setdefault(("audio", fused), []).append(event_ms(lambda: aud.forward_into(mels, ea), 8, warmup=2))
-for (what, fused), t in sorted(res.items()):
+
+
+def concurrent():
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        aud.forward_into(mels, ea)
+    vis.forward_into(frames, ev)
+    main.wait_stream(side)
+
+
+res = {"serial": [], "concurrent": []}
+for rnd in range(4):
+    for name, fn in (("serial", serial), ("concurrent", concurrent)):
+        res[name].append(event_ms(fn, 5, warmup=2))
+        torch.cuda.synchronize()
+        assert torch.equal(ev, ref_v) and torch.equal(ea, ref_a), name
+for name, t in res.items():
     t = sorted(t)
-    print(f"{what} fused={fused}: median {t[1]:.3f} ms  min {t[0]:.3f}  -> {pairs / t[1] * 1e3:.0f} pairs/s", flush=True)
+    print(f"{name}: median {(t[1] + t[2]) / 2:.3f} ms  min {t[0]:.3f}  -> {pairs / ((t[1] + t[2]) / 2) * 1e3:.0f} pairs/s", flush=True)
