@@ -75,6 +75,10 @@ class HippoMMHipError(RuntimeError):
 
 def bind(path):
     """dlopen `path` and apply the binding table (also used by tools/ for the probe build of the same sources)."""
+    # PyTorch-ROCm ships its own HIP / HSA runtime libraries.  They must be in the process BEFORE this library pulls in the
+    # ones under /opt/rocm: loaded the other way round (library first, torch later) the library's runtime finds no device
+    # ("no ROCm-capable device is detected") although torch sees the GPU.
+    import torch  # noqa: F401
     lib = C.CDLL(str(path))
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI and the binding disagree

@@ -6,6 +6,10 @@
 //   mode 1  16 x v_mfma_f32_32x32x16_bf16, operands held in registers
 //   mode 2  as 0, operands re-read from LDS every step (12 ds_read_b128 per step: the real kernel's ratio)
 //   mode 3  as 1, operands re-read from LDS every step (12 ds_read_b128 per step)
+//   mode 4  as 0, but the operands CHANGE every step (each fragment register is XOR-ed with a step-dependent mask of its low
+//           mantissa / sign bits: 12 VALU per 32 MFMAs) -- modes 0-3 keep the multiplier inputs static, which is not what a
+//           GEMM does to them
+//   mode 6  as 2, reading a different 12-fragment set every step (8 sets = 96 KiB of LDS per workgroup... per wave 12 KiB x 8)
 // Operand values are pseudo-random bf16 in (-1, 1) (zeros would draw far less power).  Per workgroup the kernel stamps
 // s_memtime (shader clock) and s_memrealtime (100 MHz) around the loop: clock = d(memtime) / d(realtime) * 100 MHz.
 #include "hmm_common.h"
@@ -44,12 +48,28 @@ __global__ __launch_bounds__(512) void mfma_power_kernel(int steps, float* __res
         for (int j = 0; j < 16; ++j) v[j] = 0.f;
 
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    const bf16x8* frag0 = reinterpret_cast<const bf16x8*>(smem) + lane;
     for (int st = 0; st < steps; ++st) {
-        if constexpr (MODE >= 2) {
+        if constexpr (MODE == 2 || MODE == 3) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const volatile bf16x8*>(frag + i * 64);
 #pragma unroll
             for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const volatile bf16x8*>(frag + (8 + i) * 64);
+        }
+        if constexpr (MODE == 6) {                        // another wave's fragment set every step: the data changes, the traffic does not
+            const bf16x8* f = frag0 + ((wave + st) & 7) * 12 * 64;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const volatile bf16x8*>(f + i * 64);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const volatile bf16x8*>(f + (8 + i) * 64);
+        }
+        if constexpr (MODE == 4) {                        // flip sign and low mantissa bits of every operand register, a new mask per step
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned m = 0x80078007u * ((unsigned)st * 2654435761u >> 31) ^ (((unsigned)st * 40503u) & 0x00070007u);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { u32x4 t = __builtin_bit_cast(u32x4, a[i]); t[i & 3] ^= m; a[i] = __builtin_bit_cast(bf16x8, t); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { u32x4 t = __builtin_bit_cast(u32x4, b[i]); t[i & 3] ^= m; b[i] = __builtin_bit_cast(bf16x8, t); }
         }
         if constexpr ((MODE & 1) == 0) {
 #pragma unroll
@@ -85,12 +105,14 @@ extern "C" int hmm_probe_mfma_power(int mode, int steps, float* sink_dev, unsign
     using namespace hmm;
     hipStream_t st = static_cast<hipStream_t>(stream);
     constexpr int lds = 100 * 1024;                       // one workgroup per CU
-    HMM_REQUIRE(mode >= 0 && mode <= 3 && steps > 0 && sink_dev && ticks_dev, HMM_E_INVALID, "mfma_power: bad arguments");
+    HMM_REQUIRE(mode >= 0 && mode <= 6 && mode != 5 && steps > 0 && sink_dev && ticks_dev, HMM_E_INVALID, "mfma_power: bad arguments");
     switch (mode) {
         case 0: { HMM_ENSURE_DYN_LDS(mfma_power_kernel<0>, lds); mfma_power_kernel<0><<<256, 512, lds, st>>>(steps, sink_dev, ticks_dev); break; }
         case 1: { HMM_ENSURE_DYN_LDS(mfma_power_kernel<1>, lds); mfma_power_kernel<1><<<256, 512, lds, st>>>(steps, sink_dev, ticks_dev); break; }
         case 2: { HMM_ENSURE_DYN_LDS(mfma_power_kernel<2>, lds); mfma_power_kernel<2><<<256, 512, lds, st>>>(steps, sink_dev, ticks_dev); break; }
-        default: { HMM_ENSURE_DYN_LDS(mfma_power_kernel<3>, lds); mfma_power_kernel<3><<<256, 512, lds, st>>>(steps, sink_dev, ticks_dev); break; }
+        case 3: { HMM_ENSURE_DYN_LDS(mfma_power_kernel<3>, lds); mfma_power_kernel<3><<<256, 512, lds, st>>>(steps, sink_dev, ticks_dev); break; }
+        case 4: { HMM_ENSURE_DYN_LDS(mfma_power_kernel<4>, lds); mfma_power_kernel<4><<<256, 512, lds, st>>>(steps, sink_dev, ticks_dev); break; }
+        default: { HMM_ENSURE_DYN_LDS(mfma_power_kernel<6>, lds); mfma_power_kernel<6><<<256, 512, lds, st>>>(steps, sink_dev, ticks_dev); break; }
     }
     HMM_LAUNCH_CHECK();
     return HMM_OK;

@@ -16,7 +16,9 @@ lib.hmm_probe_mfma_power.restype = C.c_int
 lib.hmm_probe_mfma_power.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 
 NAMES = {0: "16x16x32 bf16, operands in registers", 1: "32x32x16 bf16, operands in registers",
-         2: "16x16x32 bf16 + 12 ds_read_b128 per K=32 step", 3: "32x32x16 bf16 + 12 ds_read_b128 per K=32 step"}
+         2: "16x16x32 bf16 + 12 ds_read_b128 per K=32 step", 3: "32x32x16 bf16 + 12 ds_read_b128 per K=32 step",
+         4: "16x16x32 bf16, operands in registers, CHANGING every step (xor masks)",
+         6: "16x16x32 bf16 + 12 ds_read_b128 per K=32 step of a DIFFERENT fragment set every step"}
 STEPS = 200_000                                             # ~50 ms per launch at 1.5 GHz
 FLOPS = 256 * 8 * STEPS * 2 * 128 * 64 * 32                 # per launch
 
@@ -40,7 +42,7 @@ def sample_power(stop, out):
 sink = torch.zeros(512, device="cuda")
 ticks = torch.zeros(512, dtype=torch.int64, device="cuda")
 results = []
-for mode in (0, 1, 2, 3, 0, 1):
+for mode in (0, 4, 2, 6, 1, 0, 4):
     def run():
         L.check(lib.hmm_probe_mfma_power(mode, STEPS, sink.data_ptr(), ticks.data_ptr(), L.stream_ptr()), "mfma_power")
     for _ in range(20):                                     # ~1 s: let the power controller settle
