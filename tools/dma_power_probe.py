@@ -18,7 +18,9 @@ lib.hmm_probe_dma_stream.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.c_void_p, 
 
 
 def power_files():
-    return glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input") or glob.glob("/sys/class/hwmon/hwmon*/power1_input")
+    from probe_common import own_power_file                   # this GPU's sensor only (the host's sysfs lists all eight cards)
+    f = own_power_file()
+    return [f] if f else []
 
 
 def measure(run, secs=1.5):

@@ -24,8 +24,10 @@ FLOPS = 256 * 8 * STEPS * 2 * 128 * 64 * 32                 # per launch
 
 
 def power_files():
-    return [p for p in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")] or \
-           [p for p in glob.glob("/sys/class/hwmon/hwmon*/power1_input")]
+    """Only THIS GPU's sensor (round 2 averaged over every card of the host: its ~400 W readings were 1/8 load + 7/8 idle)."""
+    from probe_common import own_power_file
+    f = own_power_file()
+    return [f] if f else []
 
 
 def sample_power(stop, out):

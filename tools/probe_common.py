@@ -38,3 +38,18 @@ def event_ms(fn, iters, warmup=2):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
+
+
+def own_power_file():
+    """hwmon power1_input of THE GPU this process uses.  A box's sysfs lists every card of the host (eight on these nodes,
+    seven of them other people's): match the PCI address of torch's device 0 against /sys/class/drm/card*/device."""
+    import glob
+    import torch
+    pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+    want = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    for dev in glob.glob("/sys/class/drm/card*/device"):
+        if os.path.basename(os.path.realpath(dev)).lower() == want:
+            files = glob.glob(os.path.join(dev, "hwmon", "hwmon*", "power1_input"))
+            if files:
+                return files[0]
+    return None
