@@ -367,13 +367,26 @@ def retrieval_bench(rows, do_cpu):
         t0 = time.perf_counter()
         top = ask()
         t.append(time.perf_counter() - t0)
+    def ask_device_ranked():                                 # the same, the final ranking on the device (EventStore.top_hits)
+        tower.forward_into(tok([question]).cuda(), emb)
+        return events.top_hits(emb[0], 5, 5)
+
+    ask_device_ranked()
+    t2 = []
+    for _ in range(7):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        top2 = ask_device_ranked()
+        t2.append(time.perf_counter() - t0)
     t_tower = event_time_ms(lambda: tower.forward_into(tok([question]).cuda(), emb), 10, warmup=2)
     q = emb[0].clone()
     t_scan = event_time_ms(lambda: events.search_segments_device(q, events.offsets, 5), 10, warmup=2)
     out = {"what": "question -> tokenizer -> text tower (24 blocks, batch 1) -> top-5 per event over 2000 events x 500 rows "
                    "(one pass) -> best 5 hits on the host",
            "ms_end_to_end": round(sorted(t)[len(t) // 2] * 1e3, 3), "ms_text_tower": round(t_tower, 3),
-           "ms_per_event_scan_all_events": round(t_scan, 3), "events": n_events, "rows": n_events * per_event}
+           "ms_per_event_scan_all_events": round(t_scan, 3), "events": n_events, "rows": n_events * per_event,
+           "ms_end_to_end_ranked_on_device": round(sorted(t2)[len(t2) // 2] * 1e3, 3),
+           "device_ranking_equals_host_ranking": [(e, i) for e, i, _ in top2] == [(e, i) for _, e, i in top]}
     if do_cpu:
         from oracle import imagebind_oracle as ib
         from oracle.vector_ops_oracle import top_k_cosine_similarity_oracle

@@ -216,6 +216,27 @@ class EventStore(FeatureStore):
         self.offsets = torch.tensor(np.concatenate([[0], np.cumsum(self.lengths)]), dtype=torch.int64, device=rows.device)
         return self
 
+    def top_hits(self, query, k: int = 5, keep: int = 5):
+        """The caller's whole step in one go (hippocampal_memory.py:3143-3153 + :3275-3277): top-k per event, then every hit of
+        every event ranked by similarity and the best `keep` returned as [(event index, row inside the event, similarity)].
+        The ranking runs on the device (a stable descending sort of the (E, k) similarities in event order, i.e. what Python's
+        stable ``sorted(..., reverse=True)`` does to the list the reference builds event by event); only `keep` hits are read
+        back.  NaN similarities (zero-norm rows) rank first, as they do per event."""
+        q = _query_to_device(query, self.rows.device)
+        idx, sims, counts = self.search_segments_device(q, self.offsets, int(k))
+        E = idx.shape[0]
+        if E == 0:
+            return []
+        slot = torch.arange(idx.shape[1], device=idx.device).unsqueeze(0)
+        valid = slot < counts.unsqueeze(1)
+        key = torch.where(valid, torch.nan_to_num(sims, nan=float("inf")), torch.full_like(sims, float("-inf"))).reshape(-1)
+        order = torch.sort(key, descending=True, stable=True).indices[: int(keep)]
+        order = order[valid.reshape(-1)[order]]                 # fewer than `keep` hits in the whole store
+        ev = (order // idx.shape[1]).cpu().tolist()
+        rows = idx.reshape(-1)[order].cpu().tolist()
+        vals = sims.reshape(-1)[order].cpu().tolist()
+        return list(zip(ev, rows, vals))
+
     def top_k_per_event(self, query, k: int = 5):
         """[(indices int64[k_e], sims float32[k_e]) for every event], each exactly what
         ``top_k_cosine_similarity(query, event_features, k)`` returns for that event."""

@@ -129,3 +129,11 @@ def test_question_to_hits_over_250_events_and_120k_rows(query):
         np.testing.assert_allclose(sims, w_sims, rtol=0, atol=2e-6)
         _same_rows_where_separated(query, ev.astype(np.float64), idx, sims, w_idx)
     assert [(e, i) for _, e, i in _ranked(got)] == [(e, i) for _, e, i in _ranked(want)]
+    # the same final step on the device: only the five hits come back
+    store = EventStore(events)
+    hits = store.top_hits(query, k=5, keep=5)
+    assert [(e, i) for e, i, _ in hits] == [(e, i) for _, e, i in _ranked(want)]
+    np.testing.assert_allclose([s for _, _, s in hits], [s for s, _, _ in _ranked(want)], rtol=0, atol=2e-6)
+    assert len(store.top_hits(query, k=5, keep=100000)) == sum(min(5, n) for n in sizes)       # keep > all hits: every hit, ranked
+    few = EventStore([events[0][:2], np.zeros((0, 1024), np.float32)])
+    assert [(e, i) for e, i, _ in few.top_hits(query, 5, 5)] == [(0, int(i)) for i in top_k_cosine_similarity_oracle(query, events[0][:2], 5)[0]]
