@@ -66,18 +66,26 @@ REHEARSAL = os.environ.get("HMM_BENCH_REHEARSAL") == "1"
 # ------------------------------------------------------------------------------------------------
 # launching
 # ------------------------------------------------------------------------------------------------
-def visible_gpu_count(topology: str = "/sys/class/kfd/kfd/topology/nodes") -> int:
+def visible_gpu_count(topology: str = "/sys/class/kfd/kfd/topology/nodes", dri: str = "/dev/dri") -> int:
     """GPUs this process would see, counted WITHOUT opening the HIP runtime (the self-launching parent must never touch the
-    GPU): the KFD topology in sysfs lists one node per agent, GPUs are the nodes with SIMDs; ROCR_VISIBLE_DEVICES /
-    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow the set exactly as the runtime would apply them."""
+    GPU).  The KFD topology in sysfs lists one node per agent of the HOST, GPUs are the nodes with SIMDs; inside a container
+    only the GPUs whose render node (`drm_render_minor`) is mapped and accessible under /dev/dri are usable, so those are the
+    ones counted; ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow the set as the runtime would."""
     n = 0
+    have_dri = os.path.isdir(dri)
     for path in glob.glob(os.path.join(topology, "*", "properties")):
         try:
             props = dict(line.split(None, 1) for line in open(path).read().splitlines() if " " in line)
         except OSError:
             continue
-        if int(props.get("simd_count", "0")) > 0:
-            n += 1
+        if int(props.get("simd_count", "0")) <= 0:
+            continue
+        minor = props.get("drm_render_minor")
+        if have_dri and minor is not None:
+            node = os.path.join(dri, f"renderD{int(minor)}")
+            if not (os.path.exists(node) and os.access(node, os.R_OK | os.W_OK)):
+                continue
+        n += 1
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         val = os.environ.get(var)
         if val is not None:

@@ -124,7 +124,20 @@ def test_gpu_count_comes_from_sysfs_not_from_hip(tmp_path, monkeypatch):
         (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         monkeypatch.delenv(var, raising=False)
-    assert bench.visible_gpu_count(str(tmp_path)) == 3
+    none = str(tmp_path / "no_dri")
+    assert bench.visible_gpu_count(str(tmp_path), none) == 3
+    # a container maps only its own GPUs' render nodes: the host's other cards are in the topology but not usable
+    dri = tmp_path / "dri"
+    dri.mkdir()
+    for i, minor in ((1, 128), (2, 129), (3, 130)):
+        p = tmp_path / str(i) / "properties"
+        p.write_text(p.read_text() + f"drm_render_minor {minor}\n")
+    (dri / "renderD129").write_text("")
+    assert bench.visible_gpu_count(str(tmp_path), str(dri)) == 1
+    (dri / "renderD128").write_text("")
+    assert bench.visible_gpu_count(str(tmp_path), str(dri)) == 2
+    import functools
+    monkeypatch.setattr(bench, "visible_gpu_count", functools.partial(bench.visible_gpu_count, dri=none))
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
     assert bench.visible_gpu_count(str(tmp_path)) == 2
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")

@@ -67,3 +67,14 @@ def test_rccl_sharded_top_k(nccl_group):
     idx, sims = sharding.sharded_top_k(q, 7, len(fs), 0, fs.search_keys_device)
     assert idx.cpu().tolist() == want_idx.tolist()
     np.testing.assert_array_equal(sims.cpu().numpy(), want_sims)
+
+
+def test_launcher_counts_the_usable_gpus_without_hip():
+    """bench.py's self-launching parent counts GPUs from sysfs + the mapped render nodes; on the box that must be what the
+    runtime reports (the host's other cards are in the KFD topology but their render nodes are not in the container), and the
+    library accepts the device it is built for."""
+    import bench
+    import torch
+    from hippomm_amd import _lib
+    assert bench.visible_gpu_count() == torch.cuda.device_count() >= 1
+    assert _lib.load().hmm_device_supported() == 0
