@@ -181,6 +181,20 @@ def profile_summary(pattern: str, kernel: str):
     return None, None
 
 
+def rank_proof(world: int, rank: int, local_rank: int, n_frames: int):
+    """Self-proving N (every rank calls this): a sum of ones over the data-path backend, every rank's device, and the shard each
+    one encoded."""
+    ones = torch.ones(1, dtype=torch.int32, device="cuda")
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
+            "gcn_arch": getattr(props, "gcnArchName", None), "pci_bus_id": getattr(props, "pci_bus_id", None),
+            "frames": n_frames}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    return {"backend": dist.get_backend(), "all_reduced_rank_count": int(ones.item()), "ranks": everyone}
+
+
 def committed_n1_value(workload: str):
     """The 1-GPU value of the same workload that is on disk: the driver's newest BENCH_r*.json (cfg2, the default run) or a
     committed profiles/*bench_line*.json of that workload -> {"value", "source"} or None."""
@@ -535,7 +549,7 @@ def torch_rocm_reference():
     return out
 
 
-def sharded_scan_bench(rank, world, reduce_max):
+def sharded_scan_bench(rank, world, reduce_max, rows_per_gpu=None):
     """The 1M x 1024 scan at N GPUs (north_star: both metrics at 1 / 2 / 4 / 8 GPUs).  The store is row-sharded
     (hippomm_amd.sharding.sharded_top_k): every rank scans its shard, ONE all-gather of k packed keys (8 k bytes)
     and of the row offsets per query, the same merge on every rank.  Two shapes: 1M rows per GPU (weak; the aggregate
@@ -553,7 +567,8 @@ def sharded_scan_bench(rank, world, reduce_max):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
-    for tag, n_local in (("weak_1M_rows_per_gpu", SCAN_ROWS), ("strong_1M_rows_total", SCAN_ROWS // world)):
+    base_rows = rows_per_gpu or SCAN_ROWS                        # tests pass a small store
+    for tag, n_local in (("weak_1M_rows_per_gpu", base_rows), ("strong_1M_rows_total", base_rows // world)):
         rows = store = None
         err = None
         try:
@@ -680,18 +695,7 @@ def main():
                                                        (dist.barrier if world > 1 else (lambda: None)), reduce_max)
     kept = kept_buf[: int(n_kept.item())].clone()
 
-    proof = None
-    if world > 1:
-        # self-proving N: a sum of ones over the data-path backend, every rank's device, and the shard each one encoded
-        ones = torch.ones(1, dtype=torch.int32, device="cuda")
-        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
-        props = torch.cuda.get_device_properties(torch.cuda.current_device())
-        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
-                "gcn_arch": getattr(props, "gcnArchName", None), "pci_bus_id": getattr(props, "pci_bus_id", None),
-                "frames": hi - lo}
-        everyone = [None] * world
-        dist.all_gather_object(everyone, mine)
-        proof = {"backend": dist.get_backend(), "all_reduced_rank_count": int(ones.item()), "ranks": everyone}
+    proof = rank_proof(world, rank, local_rank, hi - lo) if world > 1 else None
 
     gather_ms = None
     sharded_scan = None

@@ -69,6 +69,21 @@ def test_rccl_sharded_top_k(nccl_group):
     np.testing.assert_array_equal(sims.cpu().numpy(), want_sims)
 
 
+def test_bench_multi_gpu_legs_over_rccl(nccl_group):
+    """The code bench.py runs at N > 1 -- the rank proof (all-reduced count, gathered per-rank records) and the row-sharded scan
+    leg with its failure agreement -- over the real RCCL backend (world size 1 is what a 1-GPU box offers; the two-rank logic runs
+    over gloo in tests/test_gpu_bench_rehearsal.py)."""
+    import bench
+    proof = bench.rank_proof(1, 0, 0, 256)
+    assert proof["backend"] == "nccl" and proof["all_reduced_rank_count"] == 1
+    assert proof["ranks"][0]["frames"] == 256 and "MI355X" in proof["ranks"][0]["name"] or proof["ranks"][0]["gcn_arch"].startswith("gfx950")
+    scan = bench.sharded_scan_bench(0, 1, lambda x: x, rows_per_gpu=250_000)
+    assert "error" not in scan, scan
+    for tag in ("weak_1M_rows_per_gpu", "strong_1M_rows_total"):
+        assert scan[tag]["rows_per_gpu"] == 250_000 and scan[tag]["indices_match_torch_where_separated"] is True
+    assert scan["value"] == scan["weak_1M_rows_per_gpu"]["GBps_all_gpus"] > 0
+
+
 def test_launcher_counts_the_usable_gpus_without_hip():
     """bench.py's self-launching parent counts GPUs from sysfs + the mapped render nodes; on the box that must be what the
     runtime reports (the host's other cards are in the KFD topology but their render nodes are not in the container), and the
