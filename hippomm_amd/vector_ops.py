@@ -170,18 +170,27 @@ def top_k_cosine_similarity(
 
     a: (1024,) query (numpy or torch); b: (N,1024) store (numpy, torch, or a resident
     FeatureStore; a 1-D b is one row, as at :173-174).  Returns (indices int64[k'],
-    similarities[k']), k' = min(k, N), best first; similarities are float64 when either input was
+    similarities[k']), k' = min(k, N) (k = 0: all N rows, k < 0: N - |k| rows, as the reference's slice gives), best first;
+    similarities are float64 when either input was
     float64 (numpy's promotion at :182) and float32 otherwise.  Ties: higher row index first; a zero-norm
     row yields NaN and ranks first, as in the reference.  (The reference leaves the order INSIDE a tie group to numpy's
     unstable argsort; this total order is the library's own rule, include/hippomm_hip.h.)
     """
-    store = b if isinstance(b, FeatureStore) else FeatureStore(b)
     a_is64 = (isinstance(a, np.ndarray) and a.dtype == np.float64) or (
         isinstance(a, torch.Tensor) and a.dtype == torch.float64)
-    idx, sims = store.search(a, int(k))
-    if a_is64 or store.source_dtype == np.float64:
-        sims = sims.astype(np.float64)
-    return idx.astype(np.int64, copy=False), sims
+    if not isinstance(b, FeatureStore) and getattr(b, "ndim", 2) == 2 and len(b) == 0:
+        n, b_is64 = 0, str(getattr(b, "dtype", "")).endswith("float64")
+    else:
+        store = b if isinstance(b, FeatureStore) else FeatureStore(b)
+        n, b_is64 = len(store), store.source_dtype == np.float64
+    # the reference slices argsort(sims)[-k:][::-1] (:185): k = 0 keeps everything ([-0:]), k < 0 the best N - |k| rows
+    k = int(k)
+    k_eff = n if k == 0 else (max(n + k, 0) if k < 0 else min(k, n))
+    out_dtype = np.float64 if (a_is64 or b_is64) else np.float32
+    if k_eff == 0:
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=out_dtype)
+    idx, sims = store.search(a, k_eff)
+    return idx.astype(np.int64, copy=False), sims.astype(out_dtype, copy=False)
 
 
 class EventStore(FeatureStore):

@@ -70,5 +70,7 @@ def scan_order_key(sims: np.ndarray) -> np.ndarray:
 def top_k_documented_order(sims: np.ndarray, k: int):
     """Top-k under ``scan_order_key`` (ties -> higher index first, NaN first)."""
     key = scan_order_key(sims)
-    order = np.argsort(key, kind="stable")[::-1][: min(k, key.shape[0])]
+    n = key.shape[0]
+    k_eff = n if k == 0 else (max(n + k, 0) if k < 0 else min(k, n))      # the reference's slice [-k:] (vector_ops.py:185)
+    order = np.argsort(key, kind="stable")[::-1][:k_eff]
     return order.astype(np.int64), np.asarray(sims)[order]

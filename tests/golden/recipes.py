@@ -67,6 +67,15 @@ def scan_case(name: str):
         if name.endswith("f64"):
             store = store.astype(np.float64)
         return query, store, 5
+    if name in ("k_zero", "k_negative", "k_more_negative_than_n", "empty_store"):
+        # what the reference's slice argsort(sims)[-k:][::-1] (vector_ops.py:185) does outside 1 <= k: k = 0 returns ALL rows
+        # ([-0:] is the whole array), k < 0 the best N - |k| rows, nothing when |k| >= N; an empty store returns nothing
+        rng = np.random.default_rng(14)
+        store = rng.standard_normal((9, D), dtype=np.float32)
+        query = rng.standard_normal(D, dtype=np.float32)
+        if name == "empty_store":
+            return query, np.zeros((0, D), np.float32), 5
+        return query, store, {"k_zero": 0, "k_negative": -3, "k_more_negative_than_n": -20}[name]
     if name == "k_gt_n":
         rng = np.random.default_rng(5)
         return rng.standard_normal(D, dtype=np.float32), rng.standard_normal((7, D), dtype=np.float32), 32
@@ -91,7 +100,8 @@ def scan_case(name: str):
 SCAN_CASES = ["n4096_k5", "n4096_k32", "n4096_k32_f64store", "n300_k5_unitrows",
               "k_gt_n", "store_1d", "duplicate_rows", "zero_row",
               "n1000_k5_unitrows_audio20", "n2500_k5_unitrows", "n64_k5_event", "n777_k32_unitrows_f64",
-              "n32_k5_textquery", "n150_k5_textquery", "n450_k5_textquery", "n3600_k5_textquery_f64"]
+              "n32_k5_textquery", "n150_k5_textquery", "n450_k5_textquery", "n3600_k5_textquery_f64",
+              "k_zero", "k_negative", "k_more_negative_than_n", "empty_store"]
 
 
 # ------------------------------------------------------------- select (a7)
