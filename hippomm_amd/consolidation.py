@@ -54,7 +54,11 @@ def select_key_frames_device(features: torch.Tensor, similarity_threshold: float
 def select_key_frames(features: Union[np.ndarray, torch.Tensor], times: Optional[np.ndarray] = None,
                       similarity_threshold: float = 0.9) -> np.ndarray:
     """Same contract as the reference method: int64 indices, increasing, first is 0; ``times`` is
-    accepted and unused, as in the reference."""
+    accepted and unused, as in the reference.  Features are taken as float32, which is what the encoder hands over
+    (hippocampal_memory.py:1186, :842).  A float64 matrix (what ``load_theta_event`` yields) holds exactly-float32 values
+     and is converted without loss; the reference would then run its gram in float64, which can differ from the
+    float32 comparison only for pairs within ~1e-7 of the threshold -- the same band in which its float32 answer already
+    depends on the host's BLAS (tests/test_gpu_select.py pins that band to the fp64-accumulated definition)."""
     if len(features) <= 2:                              # :947-948
         return np.arange(len(features))
     dev = _lib.require_gpu()
