@@ -24,9 +24,10 @@ res = []
 for rnd in range(2):
     for waves, dma in ((8, 0), (4, 0), (8, 1), (4, 1)):
         run = lambda: L.check(lib.hmm_probe_mfma_tile_shape(waves, dma, STEPS, src.data_ptr(), sink.data_ptr(), ticks.data_ptr(), L.stream_ptr()), "tile_shape")
-        for _ in range(6):
-            run()
-        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 2.0:                 # the power sensor settles over a second or two
+            run(); run()
+            torch.cuda.synchronize()
         watts, stop = [], threading.Event()
 
         def sample():
@@ -40,11 +41,11 @@ for rnd in range(2):
         th = threading.Thread(target=sample); th.start()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10):
+        for _ in range(24):
             run()
         e1.record(); torch.cuda.synchronize()
         stop.set(); th.join()
-        ms = e0.elapsed_time(e1) / 10
+        ms = e0.elapsed_time(e1) / 24
         t = ticks.cpu().view(256, 2).double()
         rec = {"waves": waves, "wave_tile": "128x64" if waves == 8 else "128x128", "with_lds_fill_stream": bool(dma),
                "TFLOPs": round(FLOPS / ms / 1e9, 1), "shader_clock_MHz": round(float((t[:, 0] / t[:, 1] * 100).median()), 0),
