@@ -10,7 +10,7 @@
 
 namespace hmm {
 
-template <int WAVES, bool DMA>
+template <int WAVES, bool DMA, int DEPTH>
 __global__ __launch_bounds__(WAVES * 64) void mfma_tile_shape_kernel(int steps, const char* __restrict__ src, float* __restrict__ sink,
                                                                       unsigned long long* __restrict__ ticks) {
     constexpr int NI = WAVES == 8 ? 4 : 8;                 // 16-column blocks per wave tile (rows: always 8 blocks = 128)
@@ -57,7 +57,12 @@ __global__ __launch_bounds__(WAVES * 64) void mfma_tile_shape_kernel(int steps, 
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(region + ((off + i * 1024u) & ((2u << 20) - 1))),
                                                      (__attribute__((address_space(3))) void*)(ring + (h * NDMA + i) * 1024), 16, 0, 0);
                 off = (off + 32u * 32768u) & ((2u << 20) - 1);
-                if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                // DEPTH steps of pieces stay in flight (the data is never read, so a slot may be overwritten while it lands)
+                if constexpr (NDMA * DEPTH == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if constexpr (NDMA * DEPTH == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if constexpr (NDMA * DEPTH == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if constexpr (NDMA * DEPTH == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             }
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(WAVES * 64) void mfma_tile_shape_kernel(int steps, 
 
 }  // namespace hmm
 
-extern "C" int hmm_probe_mfma_tile_shape(int waves, int dma, int steps, const void* src_dev, float* sink_dev,
+extern "C" int hmm_probe_mfma_tile_shape(int waves, int dma /* 0 = no stream, d = d steps of pieces in flight (1..3) */, int steps, const void* src_dev, float* sink_dev,
                                          unsigned long long* ticks_dev, hmm_stream_t stream) {
     using namespace hmm;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -85,10 +90,11 @@ extern "C" int hmm_probe_mfma_tile_shape(int waves, int dma, int steps, const vo
                 "mfma_tile_shape: bad arguments");
     constexpr int lds = 150 * 1024;                        // one workgroup per CU
     const char* src = static_cast<const char*>(src_dev);
-#define HMM_GO(W, D) do { HMM_ENSURE_DYN_LDS((mfma_tile_shape_kernel<W, D>), lds); \
-                          mfma_tile_shape_kernel<W, D><<<256, W * 64, lds, st>>>(steps, src, sink_dev, ticks_dev); } while (0)
-    if (waves == 8) { if (dma) HMM_GO(8, true); else HMM_GO(8, false); }
-    else            { if (dma) HMM_GO(4, true); else HMM_GO(4, false); }
+#define HMM_GO(W, D, P) do { HMM_ENSURE_DYN_LDS((mfma_tile_shape_kernel<W, D, P>), lds); \
+                             mfma_tile_shape_kernel<W, D, P><<<256, W * 64, lds, st>>>(steps, src, sink_dev, ticks_dev); } while (0)
+    HMM_REQUIRE(dma >= 0 && dma <= 3, HMM_E_INVALID, "mfma_tile_shape: dma depth %d", dma);
+    if (waves == 8) { if (dma == 0) HMM_GO(8, false, 1); else if (dma == 1) HMM_GO(8, true, 1); else if (dma == 2) HMM_GO(8, true, 2); else HMM_GO(8, true, 3); }
+    else            { if (dma == 0) HMM_GO(4, false, 1); else if (dma == 1) HMM_GO(4, true, 1); else if (dma == 2) HMM_GO(4, true, 2); else HMM_GO(4, true, 3); }
 #undef HMM_GO
     HMM_LAUNCH_CHECK();
     return HMM_OK;

@@ -21,8 +21,8 @@ sink = torch.zeros(512, device="cuda")
 ticks = torch.zeros(512, dtype=torch.int64, device="cuda")
 pf = own_power_file()
 res = []
-for rnd in range(2):
-    for waves, dma in ((8, 0), (4, 0), (8, 1), (4, 1)):
+for rnd in range(1):
+    for waves, dma in ((8, 0), (4, 0), (8, 1), (4, 1), (8, 2), (4, 2), (8, 3), (4, 3)):
         run = lambda: L.check(lib.hmm_probe_mfma_tile_shape(waves, dma, STEPS, src.data_ptr(), sink.data_ptr(), ticks.data_ptr(), L.stream_ptr()), "tile_shape")
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 2.0:                 # the power sensor settles over a second or two
@@ -47,7 +47,7 @@ for rnd in range(2):
         stop.set(); th.join()
         ms = e0.elapsed_time(e1) / 24
         t = ticks.cpu().view(256, 2).double()
-        rec = {"waves": waves, "wave_tile": "128x64" if waves == 8 else "128x128", "with_lds_fill_stream": bool(dma),
+        rec = {"waves": waves, "wave_tile": "128x64" if waves == 8 else "128x128", "with_lds_fill_stream": bool(dma), "steps_of_fill_in_flight": dma,
                "TFLOPs": round(FLOPS / ms / 1e9, 1), "shader_clock_MHz": round(float((t[:, 0] / t[:, 1] * 100).median()), 0),
                "board_W": round(sum(watts) / len(watts), 0) if watts else None, "ms_per_launch": round(ms, 2),
                "lds_read_TB_per_s": round(256 * STEPS * waves * (12 if waves == 8 else 16) * 1024 / ms / 1e9, 1),
