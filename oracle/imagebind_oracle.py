@@ -13,7 +13,9 @@ names, so a real checkpoint can be loaded into it later to validate it.
 Independent cross-check (not a pin to the reference): tests/test_oracle_vs_hf_clip.py renames the weights of
 HuggingFace ``transformers``' CLIP vision / text models -- the same architecture family, written independently --
 to these keys and finds this file's ``vision_forward`` / ``text_forward`` equal to them to < 2e-5 on unit rows.
-The audio tower (add_bias_kv attention, stem LayerNorm, clip averaging) has no such counterpart here.
+For the audio tower tests/test_oracle_vs_hf_ast.py does the same with ``transformers``' Audio Spectrogram Transformer for what the
+two share (the Conv2d patch grid and its flattening order, the blocks at 768 / 12 heads / 3072); add_bias_kv attention, the
+stem LayerNorm and the clip averaging have no such counterpart here.
 
 Upstream structure restated here (imagebind/models/imagebind_model.py
 ``ImageBindModel`` with the ``imagebind_huge()`` overrides; transformer.py
