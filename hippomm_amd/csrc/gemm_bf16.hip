@@ -254,6 +254,83 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Few rows (one question through the text tower: 77 token rows; a handful of frames): the tiled kernels put
+// ceil(M/128) x N/128 workgroups on 256 CUs and each of them walks K behind ONE LDS-DMA stage, i.e. one memory latency per
+// 64 columns of K -- the text tower's fc2 (M = 77, N = 1024, K = 4096) is 8 workgroups x 64 steps = 60 us for 0.65 GFLOP,
+// and a question's 24 blocks take 3.2 ms.  Here ONE WAVE owns a (16 MT) x 16 output sliver and streams its operands
+// straight from L2 into MFMA fragments (a lane's fragment is 16 contiguous bytes of a row: no LDS, no barrier), DEPTH
+// K-steps in flight per wave, a few waves per SIMD: N/16 x ceil(M / 16 MT) one-wave workgroups cover the chip and the
+// kernel is bound by what L2 delivers, not by a latency chain.  The workgroups that share a 16-row slice of W sit on one
+// XCD (same blockIdx % 8), so a weight byte leaves HBM once.  Same instruction, operand roles, fragment layout and K order
+// as the tiled kernels: an output element gets the same bits (tests/test_gpu_ops.py compares them bitwise).
+template <int EPI, int MT, int DEPTH>
+__global__ __launch_bounds__(64) void gemm_bf16_sliver_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+    void* __restrict__ Cout, int M, int N, int K, int tiles_m, GemmAux aux) {
+    const int lane = threadIdx.x;
+    const int frow = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int m0 = (j % tiles_m) * (16 * MT), n0 = ((j / tiles_m) * 8 + xcd) * 16;
+
+    const bf16_t* wp = W + (size_t)(n0 + frow) * K + 8 * g;
+    const bf16_t* ap[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int gm = m0 + 16 * t + frow;
+        gm = gm < M ? gm : M - 1;                       // clamp: rows past M are never stored
+        ap[t] = A + (size_t)gm * K + 8 * g;
+    }
+
+    bf16x8 wf[DEPTH][2], af[DEPTH][MT][2];
+    auto load = [&](int slot, int kt) {
+        wf[slot][0] = *reinterpret_cast<const bf16x8*>(wp + kt * 64);
+        wf[slot][1] = *reinterpret_cast<const bf16x8*>(wp + kt * 64 + 32);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            af[slot][t][0] = *reinterpret_cast<const bf16x8*>(ap[t] + kt * 64);
+            af[slot][t][1] = *reinterpret_cast<const bf16x8*>(ap[t] + kt * 64 + 32);
+        }
+    };
+
+    f32x4 acc[MT][1];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int KT = K >> 6;
+    // the first DEPTH steps, unconditionally (steps past the end of a short K re-load the last one and are never used): with a
+    // branch here the compiler no longer knows how many loads are in flight at the loop header below
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) load(s, s < KT ? s : KT - 1);
+    auto step = [&](int s) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][kh], af[s][t][kh], acc[t][0], 0, 0, 0);
+    };
+    int kt0 = 0;
+    // steady state without a branch in it, so that the compiler counts the loads in flight (vmcnt(4 (DEPTH-1)) style waits)
+    // instead of draining them at every use
+    for (; kt0 + 2 * DEPTH <= KT; kt0 += DEPTH) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            step(s);
+            load(s, kt0 + s + DEPTH);
+        }
+    }
+    for (; kt0 < KT; kt0 += DEPTH) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            const int kt = kt0 + s;
+            if (kt < KT) {
+                step(s);
+                if (kt + DEPTH < KT) load(s, kt + DEPTH);
+            }
+        }
+    }
+    gemm_epilogue<EPI, MT, 1>(acc, bias, Cout, M, N, m0 + frow, n0 + 4 * g, aux);
+}
 
 // LDS-transposed epilogue of the ping-pong kernel.  The MFMA leaves a lane with 4 consecutive
 // columns of 16 different rows, so direct stores are 8-B (bf16) pieces of 16 rows per instruction:
@@ -603,6 +680,53 @@ static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void
     return HMM_OK;
 }
 
+// Rows per wave of the sliver kernel (16 MT) and whether it beats the tiled kernels, from two fitted lines
+// (tools/sliver_probe.py, profiles/r3_sliver_probe.json): a wave reads its fragments from L2 unshared, so the kernel moves
+// waves x K x (MT + 1) x 32 B at ~8.5 TB/s chip-wide (more when fewer than ~192 waves are in flight) after ~3 us of launch and
+// first-load latency; one round of 128x128 tiles takes ~4.5 us + 0.55 us per 64 columns of K, whatever M and N are.
+HMM_TUNABLE(int, g_gemm_sliver_mt, 0)    // probe build: force 16 / 32 / 64 rows per wave (1 / 2 / 4)
+HMM_TUNABLE(int, g_gemm_sliver_auto, 1)  // probe build: 0 = the dispatcher never picks the sliver kernel
+static float sliver_us(int M, int N, int K, int mt) {
+    const long waves = (long)((M + 16 * mt - 1) / (16 * mt)) * (N / 16);
+    const float stream = (float)waves * K * (mt + 1) * 32.0f / 8.5e6f;
+    return 3.0f + stream * (waves < 192 ? 192.0f / waves : 1.0f);
+}
+static int sliver_mt(int M, int N, int K) {
+    if (g_gemm_sliver_mt > 0) return g_gemm_sliver_mt;
+    int best = 1;
+    for (int mt = 2; mt <= 4 && 16 * (mt / 2) < M; mt *= 2)
+        if (sliver_us(M, N, K, mt) < sliver_us(M, N, K, best)) best = mt;
+    return best;
+}
+static bool sliver_wins(int M, int N, int K, int epi) {
+    if (!g_gemm_sliver_auto || epi > HMM_EPI_F32) return false;
+    return sliver_us(M, N, K, sliver_mt(M, N, K)) < 0.95f * (4.5f + 0.55f * (K >> 6));
+}
+
+template <int EPI>
+static int launch_gemm_sliver(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                              const GemmAux& aux, hipStream_t st) {
+    const int mt = sliver_mt(M, N, K);
+    const int tiles_m = (M + 16 * mt - 1) / (16 * mt), grid = tiles_m * (N / 16);
+    if (mt == 1) gemm_bf16_sliver_kernel<EPI, 1, 8><<<grid, 64, 0, st>>>(A, W, bias, C, M, N, K, tiles_m, aux);
+    else if (mt == 2) gemm_bf16_sliver_kernel<EPI, 2, 6><<<grid, 64, 0, st>>>(A, W, bias, C, M, N, K, tiles_m, aux);
+    else gemm_bf16_sliver_kernel<EPI, 4, 4><<<grid, 64, 0, st>>>(A, W, bias, C, M, N, K, tiles_m, aux);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+
+static int launch_gemm_sliver_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                                  int epi, const GemmAux& aux, hipStream_t st) {
+    switch (epi) {
+        case HMM_EPI_BIAS_BF16:      return launch_gemm_sliver<HMM_EPI_BIAS_BF16>(A, W, bias, C, M, N, K, aux, st);
+        case HMM_EPI_BIAS_GELU_BF16: return launch_gemm_sliver<HMM_EPI_BIAS_GELU_BF16>(A, W, bias, C, M, N, K, aux, st);
+        case HMM_EPI_BIAS_RESID_F32: return launch_gemm_sliver<HMM_EPI_BIAS_RESID_F32>(A, W, bias, C, M, N, K, aux, st);
+        case HMM_EPI_F32:            return launch_gemm_sliver<HMM_EPI_F32>(A, W, bias, C, M, N, K, aux, st);
+    }
+    set_error("gemm: the sliver kernel has no epilogue %d", epi);
+    return HMM_E_INVALID;
+}
+
 #define HMM_EPI_SWITCH(CALL)                                                              \
     switch (epi) {                                                                        \
         case HMM_EPI_BIAS_BF16:      return CALL(HMM_EPI_BIAS_BF16);                      \
@@ -656,7 +780,9 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
         const long tiles = (long)tiles_m * tiles_n;
         // few 256x256 tiles (cls-only last block, head): 128x128 tiles put 4x more CUs to work
-        if (tiles < 128) return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
+        if (tiles < 128)
+            return sliver_wins(M, N, K, epi) ? launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, aux, st)
+                                             : launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
         // peel p <= 2 row tiles when that leaves the main launch with a last round that is full or nearly full (>= 240 of 256
         // CUs) instead of a nearly empty one
         int peel = 0;
@@ -681,6 +807,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
                                                epi, tail, st);
     }
     switch (tile) {
+        case HMM_GEMM_TILE_SLIVER:     return launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_256x256_PP: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_128x128:    return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_256x128:    return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);

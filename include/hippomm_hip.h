@@ -238,6 +238,7 @@ int hmm_op_gemm_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* 
 #define HMM_GEMM_TILE_256x256     2  /* 8 waves, same loop                                                */
 #define HMM_GEMM_TILE_256x256_PP  3  /* 8 waves, 4-phase ping-pong, counted vmcnt; needs N%256==0, K%128==0 */
 #define HMM_GEMM_TILE_PP_PEELED   4  /* what AUTO uses for large shapes: PP on whole rounds + 128x128 tail */
+#define HMM_GEMM_TILE_SLIVER      5  /* few rows: one wave per 16..64 x 16 sliver, operands from L2 straight into fragments; epilogues 0..3 */
 int hmm_op_gemm_bf16_tile(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
                           void* c_dev, int M, int N, int K, int epilogue, int tile, hmm_stream_t stream);
 /* y_bf16[rows, D] = LayerNorm(x_f32[rows, D]) * gamma + beta ; D in {768, 1280} */

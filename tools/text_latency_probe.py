@@ -1,0 +1,68 @@
+"""One question through the text tower (24 blocks, 77 token rows): latency with the few-row GEMMs on the tiled kernels and on
+the sliver kernel, eager and as a replayed HIP graph; the same for 2 and 4 questions and for one / eight frames through the
+vision tower.  Checks that both dispatches give the same embedding bits.  Usage: python tools/text_latency_probe.py [out.json]"""
+import json
+import sys
+import time
+
+import torch
+
+from probe_common import load_probe, setter
+
+L, lib = load_probe()
+set_auto = setter(lib, "g_gemm_sliver_auto")
+from hippomm_amd.encoder import HipTower, synthetic_state_dict   # noqa: E402
+
+rows = []
+
+
+def wall_ms(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / iters * 1e3
+
+
+def graph_of(tower, x, out):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        tower.forward_into(x, out)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            tower.forward_into(x, out)
+    torch.cuda.synchronize()
+    return g
+
+
+for kind, batches in (("text", (1, 2, 4, 16)), ("vision", (1, 8))):
+    sd = synthetic_state_dict((kind,), seed=99)
+    tower = HipTower(kind, sd)
+    del sd
+    for B in batches:
+        if kind == "text":
+            x = torch.randint(1, 49000, (B, 77), device="cuda")
+            x[:, 0], x[:, 20] = 49406, 49407
+        else:
+            x = torch.randn(B, 3, 224, 224, device="cuda")
+        rec = {"tower": kind, "batch": B}
+        outs = []
+        for auto in (0, 1):
+            set_auto(auto)
+            out = torch.empty(B, 1024, device="cuda")
+            tag = "sliver" if auto else "tiled"
+            rec[f"ms_eager_{tag}"] = round(wall_ms(lambda: tower.forward_into(x, out)), 3)
+            g = graph_of(tower, x, out)
+            rec[f"ms_graph_{tag}"] = round(wall_ms(g.replay), 3)
+            outs.append(out.clone())
+            del g
+        rec["same_bits"] = bool(torch.equal(outs[0], outs[1]))
+        rows.append(rec)
+        print(json.dumps(rec), flush=True)
+    del tower
+    torch.cuda.empty_cache()
+if len(sys.argv) > 1:
+    json.dump(rows, open(sys.argv[1], "w"), indent=1)
