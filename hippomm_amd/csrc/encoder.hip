@@ -416,10 +416,12 @@ extern "C" double hmm_encoder_flops_executed(const hmm_encoder* e, int batch) {
 namespace hmm {
 HMM_TUNABLE(int, g_enc_cls_fork, 1)      // probe build: 0 = cls-row projection on the chain's own stream (A/B)
 HMM_TUNABLE(int, g_enc_fold_stats, 1)    // probe build: 0 = folded-LayerNorm row statistics by a pass over xb (A/B)
+HMM_TUNABLE(int, g_enc_sliver_rows, 16448) // token rows of a forward (batch x clips x tokens) up to which few-row GEMMs may use the sliver kernel
 
 struct Chain {                 // one (half-)batch travelling through the tower on one stream
     const void* input; float* out; char* ws; WsPlan p; hipStream_t st; int batch;
     hipStream_t cls_st; hipEvent_t ev_x, ev_cls;      // fork for the cls-row projection of the fused attention path
+    int tile;                  // GEMM dispatch of this forward: HMM_GEMM_TILE_AUTO, or AUTO_TILED when the forward is large
 };
 
 #define HMM_TRY(call) do { int _rc = (call); if (_rc != HMM_OK) return _rc; } while (0)
@@ -438,7 +440,7 @@ static int chain_tokens(hmm_encoder* e, const Chain& c) {
     }
     if (e->tower == HMM_TOWER_VISION) HMM_TRY(launch_im2col_vision(static_cast<const float*>(c.input), im2col, n_img, c.st));
     else                              HMM_TRY(launch_im2col_audio(static_cast<const float*>(c.input), im2col, n_img, c.st));
-    HMM_TRY(gemm_bf16(im2col, e->patch_w, nullptr, patch, n_img * e->n_patches, D, e->patch_k_pad, HMM_EPI_F32, -1, c.st));
+    HMM_TRY(gemm_bf16(im2col, e->patch_w, nullptr, patch, n_img * e->n_patches, D, e->patch_k_pad, HMM_EPI_F32, c.tile, c.st));
     HMM_TRY(launch_assemble_tokens(patch, e->cls, e->pos, e->stem_g, e->stem_b, 1e-5f, e->pre_g, e->pre_b, 1e-6f,
                                    x, n_img, e->T, D, c.st));
     return HMM_OK;
@@ -491,23 +493,23 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
             }
             HMM_TRY(launch_gather_rows(xb, (size_t)T * D * 2, ac, n_img, D * 2, cst));
             GemmAux lc; lc.rs = rs; lc.rs_stride = T; lc.c1 = w.c1[0];
-            HMM_TRY(gemm_bf16(ac, w.wf[0], w.c2[0], hc, n_img, 3 * D, D, HMM_EPI_LN_BF16, -1, cst, &lc));
+            HMM_TRY(gemm_bf16(ac, w.wf[0], w.c2[0], hc, n_img, 3 * D, D, HMM_EPI_LN_BF16, c.tile, cst, &lc));
             if (g_enc_cls_fork) {
                 HMM_HIP_CHECK(hipEventRecord(c.ev_cls, cst));
                 HMM_HIP_CHECK(hipStreamWaitEvent(st, c.ev_cls, 0));
             }
             HMM_TRY(qkv_attention_bf16(xb, w.wf[0], w.c2[0], hc, big, n_img, st, rs, w.c1[0]));
-            HMM_TRY(gemm_bf16(big, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_XB, -1, st, &emit));
+            HMM_TRY(gemm_bf16(big, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_XB, c.tile, st, &emit));
         } else {
-            HMM_TRY(gemm_bf16(xb, w.wf[0], w.c2[0], big, R, 3 * D, D, HMM_EPI_LN_BF16, -1, st, &ln0));
+            HMM_TRY(gemm_bf16(xb, w.wf[0], w.c2[0], big, R, 3 * D, D, HMM_EPI_LN_BF16, c.tile, st, &ln0));
             HMM_TRY(attention_bf16(big, a, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st, false));
-            HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_XB, -1, st, &emit));
+            HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_XB, c.tile, st, &emit));
         }
         HMM_TRY(stats());
-        HMM_TRY(gemm_bf16(xb, w.wf[1], w.c2[1], big, R, e->mlp, D, HMM_EPI_LN_GELU_BF16, -1, st, &ln1));
+        HMM_TRY(gemm_bf16(xb, w.wf[1], w.c2[1], big, R, e->mlp, D, HMM_EPI_LN_GELU_BF16, c.tile, st, &ln1));
         const bool next_folded = i + 2 < e->depth;
         HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, next_folded ? HMM_EPI_BIAS_RESID_XB : HMM_EPI_BIAS_RESID_F32,
-                          -1, st, &emit));
+                          c.tile, st, &emit));
         if (next_folded) HMM_TRY(stats());
         return HMM_OK;
     }
@@ -524,44 +526,44 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
             HMM_HIP_CHECK(hipStreamWaitEvent(cst, c.ev_x, 0));
         }
         HMM_TRY(launch_layernorm_bf16(x, (size_t)T * D, w.ln1_g, w.ln1_b, ac, n_img, D, 1e-6f, cst));     // token 0 of every image
-        HMM_TRY(gemm_bf16(ac, w.qkv_w, w.qkv_b, hc, n_img, 3 * D, D, HMM_EPI_BIAS_BF16, -1, cst));
+        HMM_TRY(gemm_bf16(ac, w.qkv_w, w.qkv_b, hc, n_img, 3 * D, D, HMM_EPI_BIAS_BF16, c.tile, cst));
         if (g_enc_cls_fork) HMM_HIP_CHECK(hipEventRecord(c.ev_cls, cst));
         HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
         if (g_enc_cls_fork) HMM_HIP_CHECK(hipStreamWaitEvent(st, c.ev_cls, 0));
         HMM_TRY(qkv_attention_bf16(a, w.qkv_w, w.qkv_b, hc, big, n_img, st));
-        HMM_TRY(gemm_bf16(big, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, -1, st));
+        HMM_TRY(gemm_bf16(big, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, c.tile, st));
         HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
-        HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, -1, st));
-        HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, -1, st));
+        HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, c.tile, st));
+        HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, c.tile, st));
     } else if (i + 1 < e->depth && e->fused_attention && e->tower == HMM_TOWER_AUDIO && D == 768 && e->heads == 12 && T == 229 &&
                e->bias_kv) {
         // audio: in_proj + attention in one kernel per (clip, head); every row of a clip fits the 256-row tile, so there is
         // no cls side path.  Bitwise equal to the branch below.
         HMM_TRY(qkv_attention_audio_bf16(a, w.qkv_w, w.qkv_b, w.bias_k, w.bias_v, big, n_img, st));
-        HMM_TRY(gemm_bf16(big, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, -1, st));
+        HMM_TRY(gemm_bf16(big, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, c.tile, st));
         HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
-        HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, -1, st));
-        HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, -1, st));
+        HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, c.tile, st));
+        HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, c.tile, st));
     } else if (i + 1 < e->depth || text) {
-        HMM_TRY(gemm_bf16(a, w.qkv_w, w.qkv_b, big, R, 3 * D, D, HMM_EPI_BIAS_BF16, -1, st));
+        HMM_TRY(gemm_bf16(a, w.qkv_w, w.qkv_b, big, R, 3 * D, D, HMM_EPI_BIAS_BF16, c.tile, st));
         HMM_TRY(attention_bf16(big, a, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st, text));
-        HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, -1, st));
+        HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, c.tile, st));
         HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
-        HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, -1, st));
-        HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, -1, st));
+        HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, c.tile, st));
+        HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, c.tile, st));
     } else {
         // The head reads only token 0 (SelectElement(index=0)), so the LAST block needs K/V for every
         // token but Q, attention output, out-proj and the MLP for the cls row of each image only.
         // K|V projection of all rows (in_proj rows D..3D), Q projection of the cls rows (rows 0..D).
-        HMM_TRY(gemm_bf16(a, w.qkv_w + (size_t)D * D, w.qkv_b + D, big, R, 2 * D, D, HMM_EPI_BIAS_BF16, -1, st));
+        HMM_TRY(gemm_bf16(a, w.qkv_w + (size_t)D * D, w.qkv_b + D, big, R, 2 * D, D, HMM_EPI_BIAS_BF16, c.tile, st));
         HMM_TRY(launch_gather_rows(a, (size_t)T * D * 2, ac, n_img, D * 2, st));
-        HMM_TRY(gemm_bf16(ac, w.qkv_w, w.qkv_b, qc, n_img, D, D, HMM_EPI_BIAS_BF16, -1, st));
+        HMM_TRY(gemm_bf16(ac, w.qkv_w, w.qkv_b, qc, n_img, D, D, HMM_EPI_BIAS_BF16, c.tile, st));
         HMM_TRY(attention_cls_bf16(qc, big, ac, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st));
         HMM_TRY(launch_gather_rows(x, (size_t)T * D * 4, xc, n_img, D * 4, st));
-        HMM_TRY(gemm_bf16(ac, w.out_w, w.out_b, xc, n_img, D, D, HMM_EPI_BIAS_RESID_F32, -1, st));
+        HMM_TRY(gemm_bf16(ac, w.out_w, w.out_b, xc, n_img, D, D, HMM_EPI_BIAS_RESID_F32, c.tile, st));
         HMM_TRY(launch_layernorm_bf16(xc, (size_t)D, w.ln2_g, w.ln2_b, ac, n_img, D, 1e-6f, st));
-        HMM_TRY(gemm_bf16(ac, w.fc1_w, w.fc1_b, hc, n_img, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, -1, st));
-        HMM_TRY(gemm_bf16(hc, w.fc2_w, w.fc2_b, xc, n_img, D, e->mlp, HMM_EPI_BIAS_RESID_F32, -1, st));
+        HMM_TRY(gemm_bf16(ac, w.fc1_w, w.fc1_b, hc, n_img, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, c.tile, st));
+        HMM_TRY(gemm_bf16(hc, w.fc2_w, w.fc2_b, xc, n_img, D, e->mlp, HMM_EPI_BIAS_RESID_F32, c.tile, st));
     }
     return HMM_OK;
 }
@@ -576,7 +578,7 @@ static int chain_head(hmm_encoder* e, const Chain& c) {
         HMM_TRY(launch_gather_selected_rows(c.ws + p.off_x, reinterpret_cast<const int32_t*>(c.ws + p.off_sel), e->T, xc,
                                             p.n_img, e->D * 4, c.st));
     HMM_TRY(launch_layernorm_bf16(xc, (size_t)e->D, e->head_g, e->head_b, hl, p.n_img, e->D, 1e-6f, c.st));
-    HMM_TRY(gemm_bf16(hl, e->head_w, nullptr, hv, p.n_img, HMM_FEATURE_DIM, e->D, HMM_EPI_F32, -1, c.st));
+    HMM_TRY(gemm_bf16(hl, e->head_w, nullptr, hv, p.n_img, HMM_FEATURE_DIM, e->D, HMM_EPI_F32, c.tile, c.st));
     HMM_TRY(launch_l2norm_rows(hv, c.out, c.batch, e->clips, e->log_scale, c.st));
     return HMM_OK;
 }
@@ -605,6 +607,10 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
     const size_t in_bytes_per_sample = e->tower == HMM_TOWER_VISION ? (size_t)3 * 224 * 224 * 4
                                        : e->tower == HMM_TOWER_AUDIO ? (size_t)3 * 128 * 204 * 4 : (size_t)e->T * 8;
 
+    // Few-row GEMMs (cls rows, head, whole small batches) may go to the sliver kernel only when the forward is small: it is
+    // the faster kernel on an otherwise idle chip (one question: 3.2 -> 1.3 ms), but next to the big GEMMs of a large batch
+    // its unshared L2 reads cost them more than they save (batch 256: +1 %; tools/small_gemm_ab_probe.py).
+    const int tile = (int64_t)batch * e->clips * e->T <= g_enc_sliver_rows ? HMM_GEMM_TILE_AUTO : HMM_GEMM_TILE_AUTO_TILED;
     Chain chains[2];
     int n_chains = 1;
     int b0 = split_point(e, batch);
@@ -616,13 +622,13 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
         if (cap != hipStreamCaptureStatusNone) b0 = 0;
     }
     if (b0 == 0) {
-        chains[0] = Chain{input_dev, out_dev, ws, ws_plan(e, batch), st, batch, e->cls_stream[0], e->ev_x[0], e->ev_cls[0]};
+        chains[0] = Chain{input_dev, out_dev, ws, ws_plan(e, batch), st, batch, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile};
     } else {
         const WsPlan p0 = ws_plan(e, b0);
-        chains[0] = Chain{input_dev, out_dev, ws, p0, st, b0, e->cls_stream[0], e->ev_x[0], e->ev_cls[0]};
+        chains[0] = Chain{input_dev, out_dev, ws, p0, st, b0, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile};
         chains[1] = Chain{static_cast<const char*>(input_dev) + (size_t)b0 * in_bytes_per_sample, out_dev + (size_t)b0 * HMM_FEATURE_DIM,
                           ws + p0.total, ws_plan(e, batch - b0), e->side_stream, batch - b0,
-                          e->cls_stream[1], e->ev_x[1], e->ev_cls[1]};
+                          e->cls_stream[1], e->ev_x[1], e->ev_cls[1], tile};
         n_chains = 2;
         HMM_HIP_CHECK(hipEventRecord(e->ev_fork, st));                       // fork
         HMM_HIP_CHECK(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));

@@ -154,7 +154,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float*
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+// STAGES = 2: double buffer, the next K-tile is requested when the current one starts and drained before the barrier -- one
+// memory latency per 64 columns of K when a workgroup is alone on its CU (few tiles: ~0.55 us per K-tile, the text tower's
+// fc2 at K = 4096 is 40 us whatever M).  STAGES > 2: a ring with STAGES - 1 K-tiles in flight behind a counted vmcnt, one
+// barrier per K-tile; same fragment reads and MFMA order, same bits.
+template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     void* __restrict__ Cout, int M, int N, int K, int tiles_n, GemmAux aux) {
@@ -221,14 +225,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = K / 64;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
-        const char* base = smem + cur * STAGE;
+    auto compute = [&](const char* base) {
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             const int ck = kh ? c_k1 : c_k0;
@@ -245,8 +242,49 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
         }
+    };
+    if constexpr (STAGES == 2) {
+        stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
+            compute(smem + cur * STAGE);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        // Ring of STAGES K-tiles.  Iteration kt: wait for this wave's own pieces of K-tile kt (the younger K-tiles stay in
+        // flight), barrier (RAW: every wave's pieces of kt have landed; WAR: every wave has finished reading kt - 1), request
+        // K-tile kt + STAGES - 1 into the buffer kt - 1 lived in, compute kt.
+        constexpr int PER_STAGE = A_PER_WAVE + W_PER_WAVE;       // LDS-DMA instructions per wave and K-tile
+        static_assert(PER_STAGE * (STAGES - 2) <= 63, "vmcnt is a 6-bit counter");
+#pragma unroll
+        for (int st = 0; st < STAGES - 1; ++st)
+            if (st < KT) stage(st, st);
+        int buf = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            const int younger = KT - 1 - kt;                     // K-tiles requested after kt so far (at most STAGES - 2)
+            if (younger >= STAGES - 2) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (STAGES - 2)) : "memory");
+            } else if (STAGES > 3 && younger == 1) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
+            } else if (STAGES > 4 && younger == 2) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * 2) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const int nxt = kt + STAGES - 1;
+            if (nxt < KT) stage(nxt, buf == 0 ? STAGES - 1 : buf - 1);
+            compute(smem + buf * STAGE);
+            buf = buf + 1 == STAGES ? 0 : buf + 1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 
     // epilogue: lane holds C[m][n .. n+3]
@@ -668,11 +706,11 @@ static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
     return HMM_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2>
 static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                        const GemmAux& aux, hipStream_t st) {
-    constexpr int LDS = 2 * (BM + BN) * 128;
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI>;
+    constexpr int LDS = STAGES * (BM + BN) * 128;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, STAGES>;
     HMM_ENSURE_DYN_LDS(kern, LDS);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
     kern<<<tiles_m * tiles_n, WM * WN * 64, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n, aux);
@@ -686,6 +724,7 @@ static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void
 // first-load latency; one round of 128x128 tiles takes ~4.5 us + 0.55 us per 64 columns of K, whatever M and N are.
 HMM_TUNABLE(int, g_gemm_sliver_mt, 0)    // probe build: force 16 / 32 / 64 rows per wave (1 / 2 / 4)
 HMM_TUNABLE(int, g_gemm_sliver_auto, 1)  // probe build: 0 = the dispatcher never picks the sliver kernel
+HMM_TUNABLE(int, g_gemm_sliver_tiled_pct, 100)   // probe build: scale of the tiled kernels' estimate (cold weights cost them more)
 static float sliver_us(int M, int N, int K, int mt) {
     const long waves = (long)((M + 16 * mt - 1) / (16 * mt)) * (N / 16);
     const float stream = (float)waves * K * (mt + 1) * 32.0f / 8.5e6f;
@@ -700,7 +739,7 @@ static int sliver_mt(int M, int N, int K) {
 }
 static bool sliver_wins(int M, int N, int K, int epi) {
     if (!g_gemm_sliver_auto || epi > HMM_EPI_F32) return false;
-    return sliver_us(M, N, K, sliver_mt(M, N, K)) < 0.95f * (4.5f + 0.55f * (K >> 6));
+    return sliver_us(M, N, K, sliver_mt(M, N, K)) < 0.0095f * g_gemm_sliver_tiled_pct * (4.5f + 0.55f * (K >> 6));
 }
 
 template <int EPI>
@@ -748,6 +787,20 @@ static int launch_gemm_epi(const bf16_t* A, const bf16_t* W, const float* bias, 
 #undef HMM_CALL
 }
 
+// 128x128 tiles for launches of few tiles (small batches, cls rows, the peeled last row tile): a 4-deep ring instead of the
+// double buffer (128 KiB of LDS, one workgroup per CU -- these launches have fewer tiles than CUs anyway).
+HMM_TUNABLE(int, g_gemm_small_stages, 4)   // probe build: 2 = the double-buffered kernel
+static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                                 int epi, const GemmAux& aux, hipStream_t st) {
+    // 128 KiB of LDS = one workgroup per CU: more than 256 tiles would take a second round where the double-buffered kernel
+    // (two workgroups per CU) takes one
+    if (g_gemm_small_stages == 2 || (long)((M + 127) / 128) * (N / 128) > 256)
+        return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
+#define HMM_CALL(E) launch_gemm<128, 128, 2, 2, E, 4>(A, W, bias, C, M, N, K, aux, st)
+    HMM_EPI_SWITCH(HMM_CALL)
+#undef HMM_CALL
+}
+
 static int launch_gemm_pp_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                               int epi, const GemmAux& aux, hipStream_t st) {
     if ((size_t)M * K >= (1ull << 31) || (size_t)N * K >= (1ull << 31))       // 32-bit staging offsets
@@ -768,6 +821,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
     HMM_REQUIRE(epi != HMM_EPI_BIAS_RESID_XB || aux.xb != nullptr, HMM_E_INVALID, "gemm: epilogue %d needs aux.xb", epi);
     HMM_REQUIRE((epi != HMM_EPI_LN_BF16 && epi != HMM_EPI_LN_GELU_BF16) || (aux.rs != nullptr && aux.c1 != nullptr && aux.rs_stride >= 1),
                 HMM_E_INVALID, "gemm: epilogue %d needs aux.rs and aux.c1", epi);
+    const bool sliver_ok = tile == HMM_GEMM_TILE_AUTO;          // AUTO_TILED, and every named geometry: tiled kernels only
     if (tile < 0) tile = HMM_GEMM_TILE_PP_PEELED;
     const bool pp_ok = N % 256 == 0 && K % 128 == 0;
     if ((tile == HMM_GEMM_TILE_PP_PEELED || tile == HMM_GEMM_TILE_256x256_PP) && !pp_ok) tile = HMM_GEMM_TILE_256x256;
@@ -781,8 +835,8 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         const long tiles = (long)tiles_m * tiles_n;
         // few 256x256 tiles (cls-only last block, head): 128x128 tiles put 4x more CUs to work
         if (tiles < 128)
-            return sliver_wins(M, N, K, epi) ? launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, aux, st)
-                                             : launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
+            return sliver_ok && sliver_wins(M, N, K, epi) ? launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, aux, st)
+                                             : launch_gemm_small_epi(A, W, bias, C, M, N, K, epi, aux, st);
         // peel p <= 2 row tiles when that leaves the main launch with a last round that is full or nearly full (>= 240 of 256
         // CUs) instead of a nearly empty one
         int peel = 0;
@@ -802,12 +856,12 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         if (tail.xb) tail.xb += (size_t)m_main * N;
         if (tail.part) tail.part += (size_t)m_main * (N >> 6);
         if (tail.rs) tail.rs += (size_t)m_main * aux.rs_stride;
-        return launch_gemm_epi<128, 128, 2, 2>(A + (size_t)m_main * K, W, bias,
-                                               static_cast<char*>(C) + (size_t)m_main * N * (c_bf16 ? 2 : 4), M - m_main, N, K,
-                                               epi, tail, st);
+        return launch_gemm_small_epi(A + (size_t)m_main * K, W, bias,
+                                     static_cast<char*>(C) + (size_t)m_main * N * (c_bf16 ? 2 : 4), M - m_main, N, K, epi, tail, st);
     }
     switch (tile) {
         case HMM_GEMM_TILE_SLIVER:     return launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, aux, st);
+        case HMM_GEMM_TILE_128x128_RING: return launch_gemm_small_epi(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_256x256_PP: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_128x128:    return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_256x128:    return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);

@@ -232,13 +232,15 @@ int hmm_op_gemm_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* 
 /* The same product on one named tile geometry (hmm_op_gemm_bf16 picks per shape), so that every kernel the dispatcher
  * can choose is parity-tested on every shape.  Every geometry adds the K products of an output element in the same
  * order, so results are bitwise equal across geometries. */
-#define HMM_GEMM_TILE_AUTO       -1
+#define HMM_GEMM_TILE_AUTO       -1  /* by shape; few rows may go to the sliver kernel                              */
+#define HMM_GEMM_TILE_AUTO_TILED -2  /* by shape among the tiled kernels only (what a large-batch forward uses)       */
 #define HMM_GEMM_TILE_128x128     0  /* 4 waves, double-buffered LDS-DMA                                  */
 #define HMM_GEMM_TILE_256x128     1
 #define HMM_GEMM_TILE_256x256     2  /* 8 waves, same loop                                                */
 #define HMM_GEMM_TILE_256x256_PP  3  /* 8 waves, 4-phase ping-pong, counted vmcnt; needs N%256==0, K%128==0 */
 #define HMM_GEMM_TILE_PP_PEELED   4  /* what AUTO uses for large shapes: PP on whole rounds + 128x128 tail */
 #define HMM_GEMM_TILE_SLIVER      5  /* few rows: one wave per 16..64 x 16 sliver, operands from L2 straight into fragments; epilogues 0..3 */
+#define HMM_GEMM_TILE_128x128_RING 6 /* 128x128 tiles behind a 4-deep LDS-DMA ring (counted vmcnt): launches of few tiles, peeled tails */
 int hmm_op_gemm_bf16_tile(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
                           void* c_dev, int M, int N, int K, int epilogue, int tile, hmm_stream_t stream);
 /* y_bf16[rows, D] = LayerNorm(x_f32[rows, D]) * gamma + beta ; D in {768, 1280} */

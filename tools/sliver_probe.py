@@ -37,10 +37,12 @@ SHAPES = [("text qkv", 3072, 1024, "bias"), ("text out", 1024, 1024, "resid"), (
           ("text fc2", 1024, 4096, "resid"), ("vision qkv", 3840, 1280, "bias"), ("vision fc1", 5120, 1280, "gelu"),
           ("vision fc2", 1280, 5120, "resid"), ("audio fc1", 3072, 768, "gelu"), ("audio fc2", 768, 3072, "resid")]
 for name, N, K, epi in SHAPES:
-    for M in ((77, 154, 308) if name.startswith("text") else (16, 128, 192, 257, 384)):
+    for M in ((77, 154, 308, 1232) if name.startswith("text") else (16, 128, 192, 257, 384)):
         us0, c0 = run(M, N, K, epi, 0)
         usa, ca = run(M, N, K, epi, -1)
-        rec = {"gemm": name, "M": M, "N": N, "K": K, "us_128x128": round(us0, 1), "us_auto": round(usa, 1)}
+        usr, cr = run(M, N, K, epi, 6)
+        rec = {"gemm": name, "M": M, "N": N, "K": K, "us_128x128": round(us0, 1), "us_128x128_ring4": round(usr, 1),
+               "ring_same_bits": bool(torch.equal(cr, c0)), "us_auto": round(usa, 1)}
         for mt in (1, 2, 4):
             set_mt(mt)
             us, c = run(M, N, K, epi, 5)

@@ -11,6 +11,8 @@ from probe_common import load_probe, setter
 
 L, lib = load_probe()
 set_auto = setter(lib, "g_gemm_sliver_auto")
+set_stages = setter(lib, "g_gemm_small_stages")
+set_pct = setter(lib, "g_gemm_sliver_tiled_pct")
 from hippomm_amd.encoder import HipTower, synthetic_state_dict   # noqa: E402
 
 rows = []
@@ -38,7 +40,7 @@ def graph_of(tower, x, out):
     return g
 
 
-for kind, batches in (("text", (1, 2, 4, 16)), ("vision", (1, 8))):
+for kind, batches in (("text", (1, 2, 3, 4, 8, 16, 64)), ("vision", (1, 2, 4, 8, 32)), ("audio", (1, 2, 4, 8))):
     sd = synthetic_state_dict((kind,), seed=99)
     tower = HipTower(kind, sd)
     del sd
@@ -46,20 +48,21 @@ for kind, batches in (("text", (1, 2, 4, 16)), ("vision", (1, 8))):
         if kind == "text":
             x = torch.randint(1, 49000, (B, 77), device="cuda")
             x[:, 0], x[:, 20] = 49406, 49407
+        elif kind == "audio":
+            x = torch.randn(B, 3, 1, 128, 204, device="cuda")
         else:
             x = torch.randn(B, 3, 224, 224, device="cuda")
         rec = {"tower": kind, "batch": B}
         outs = []
-        for auto in (0, 1):
+        for tag, auto, stages, pct in (("tiled", 0, 2, 100), ("ring4", 0, 4, 100), ("sliver_ring4", 1, 4, 100),
+                                       ("sliver150", 1, 4, 150), ("sliver200", 1, 4, 200), ("sliver300", 1, 4, 300)):
             set_auto(auto)
+            set_stages(stages)
+            set_pct(pct)
             out = torch.empty(B, 1024, device="cuda")
-            tag = "sliver" if auto else "tiled"
             rec[f"ms_eager_{tag}"] = round(wall_ms(lambda: tower.forward_into(x, out)), 3)
-            g = graph_of(tower, x, out)
-            rec[f"ms_graph_{tag}"] = round(wall_ms(g.replay), 3)
             outs.append(out.clone())
-            del g
-        rec["same_bits"] = bool(torch.equal(outs[0], outs[1]))
+        rec["same_bits"] = all(bool(torch.equal(outs[0], o)) for o in outs[1:])
         rows.append(rec)
         print(json.dumps(rec), flush=True)
     del tower
