@@ -720,14 +720,16 @@ static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void
 
 // Rows per wave of the sliver kernel (16 MT) and whether it beats the tiled kernels, from two fitted lines
 // (tools/sliver_probe.py, profiles/r3_sliver_probe.json): a wave reads its fragments from L2 unshared, so the kernel moves
-// waves x K x (MT + 1) x 32 B at ~8.5 TB/s chip-wide (more when fewer than ~192 waves are in flight) after ~3 us of launch and
-// first-load latency; one round of 128x128 tiles takes ~4.5 us + 0.55 us per 64 columns of K, whatever M and N are.
+// waves x K x (MT + 1) x 32 B at ~7.5 TB/s chip-wide (less when fewer than ~192 waves are in flight) after ~3 us of launch and
+// first-load latency; 64x64 tiles behind the 4-deep ring -- what a launch this small would otherwise use -- take
+// ~2.8 us + 0.26 us per 64 columns of K.  The sliver kernel wins for one or two dozen rows, and for the text tower's
+// N = 1024 products at 77 rows (out-proj 5.4 vs 6.9 us, fc2 13 vs 20 us).
 HMM_TUNABLE(int, g_gemm_sliver_mt, 0)    // probe build: force 16 / 32 / 64 rows per wave (1 / 2 / 4)
 HMM_TUNABLE(int, g_gemm_sliver_auto, 1)  // probe build: 0 = the dispatcher never picks the sliver kernel
-HMM_TUNABLE(int, g_gemm_sliver_tiled_pct, 100)   // probe build: scale of the tiled kernels' estimate (cold weights cost them more)
+HMM_TUNABLE(int, g_gemm_small_64, 512)   // launches of at most this many 64x64 tiles use them (behind the ring); 0 = never
 static float sliver_us(int M, int N, int K, int mt) {
     const long waves = (long)((M + 16 * mt - 1) / (16 * mt)) * (N / 16);
-    const float stream = (float)waves * K * (mt + 1) * 32.0f / 8.5e6f;
+    const float stream = (float)waves * K * (mt + 1) * 32.0f / 7.5e6f;
     return 3.0f + stream * (waves < 192 ? 192.0f / waves : 1.0f);
 }
 static int sliver_mt(int M, int N, int K) {
@@ -739,7 +741,8 @@ static int sliver_mt(int M, int N, int K) {
 }
 static bool sliver_wins(int M, int N, int K, int epi) {
     if (!g_gemm_sliver_auto || epi > HMM_EPI_F32) return false;
-    return sliver_us(M, N, K, sliver_mt(M, N, K)) < 0.0095f * g_gemm_sliver_tiled_pct * (4.5f + 0.55f * (K >> 6));
+    if ((long)((M + 63) / 64) * (N / 64) > 512) return false;               // that many rows: never
+    return sliver_us(M, N, K, sliver_mt(M, N, K)) < 0.85f * (2.8f + 0.26f * (K >> 6));
 }
 
 template <int EPI>
@@ -787,18 +790,43 @@ static int launch_gemm_epi(const bf16_t* A, const bf16_t* W, const float* bias, 
 #undef HMM_CALL
 }
 
-// 128x128 tiles for launches of few tiles (small batches, cls rows, the peeled last row tile): a 4-deep ring instead of the
-// double buffer (128 KiB of LDS, one workgroup per CU -- these launches have fewer tiles than CUs anyway).
-HMM_TUNABLE(int, g_gemm_small_stages, 4)   // probe build: 2 = the double-buffered kernel
-static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                                 int epi, const GemmAux& aux, hipStream_t st) {
-    // 128 KiB of LDS = one workgroup per CU: more than 256 tiles would take a second round where the double-buffered kernel
-    // (two workgroups per CU) takes one
-    if (g_gemm_small_stages == 2 || (long)((M + 127) / 128) * (N / 128) > 256)
-        return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
+static int launch_gemm_ring64_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                                  int epi, const GemmAux& aux, hipStream_t st) {
+#define HMM_CALL(E) launch_gemm<64, 64, 2, 2, E, 4>(A, W, bias, C, M, N, K, aux, st)
+    switch (epi) {                                   // not RESID_XB: its chunk statistics need a 64-column wave tile
+        case HMM_EPI_BIAS_BF16:      return HMM_CALL(HMM_EPI_BIAS_BF16);
+        case HMM_EPI_BIAS_GELU_BF16: return HMM_CALL(HMM_EPI_BIAS_GELU_BF16);
+        case HMM_EPI_BIAS_RESID_F32: return HMM_CALL(HMM_EPI_BIAS_RESID_F32);
+        case HMM_EPI_F32:            return HMM_CALL(HMM_EPI_F32);
+        case HMM_EPI_LN_BF16:        return HMM_CALL(HMM_EPI_LN_BF16);
+        case HMM_EPI_LN_GELU_BF16:   return HMM_CALL(HMM_EPI_LN_GELU_BF16);
+    }
+#undef HMM_CALL
+    set_error("gemm: 64x64 tiles have no epilogue %d", epi);
+    return HMM_E_INVALID;
+}
+
+static int launch_gemm_ring128_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                                   int epi, const GemmAux& aux, hipStream_t st) {
 #define HMM_CALL(E) launch_gemm<128, 128, 2, 2, E, 4>(A, W, bias, C, M, N, K, aux, st)
     HMM_EPI_SWITCH(HMM_CALL)
 #undef HMM_CALL
+}
+
+// Launches of few tiles (small batches, cls rows, the head, the peeled last row tile of the big launches): a workgroup is alone
+// on its CU, so what counts is the latency of its own K walk.  64x64 tiles behind the 4-deep ring while there are at most 512 of
+// them (64 KiB of LDS, two per CU: ~0.26 us per K-tile, and four times the workgroups of 128x128 tiles); 128x128 tiles behind
+// the ring up to 256 tiles (128 KiB, one per CU); beyond that the double-buffered 128x128 kernel (two per CU).
+HMM_TUNABLE(int, g_gemm_small_stages, 4)   // probe build: 2 = the double-buffered kernel only
+HMM_TUNABLE(int, g_gemm_tail_64, 128)      // the peeled last row tile of a big launch uses 64x64 tiles up to this many of them
+static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                                 int epi, const GemmAux& aux, hipStream_t st, bool tail = false) {
+    if (g_gemm_small_stages == 2 || (long)((M + 127) / 128) * (N / 128) > 256)
+        return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
+    if (g_gemm_small_64 && epi != HMM_EPI_BIAS_RESID_XB &&
+        (long)((M + 63) / 64) * (N / 64) <= (tail ? g_gemm_tail_64 : g_gemm_small_64))
+        return launch_gemm_ring64_epi(A, W, bias, C, M, N, K, epi, aux, st);
+    return launch_gemm_ring128_epi(A, W, bias, C, M, N, K, epi, aux, st);
 }
 
 static int launch_gemm_pp_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
@@ -857,11 +885,13 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         if (tail.part) tail.part += (size_t)m_main * (N >> 6);
         if (tail.rs) tail.rs += (size_t)m_main * aux.rs_stride;
         return launch_gemm_small_epi(A + (size_t)m_main * K, W, bias,
-                                     static_cast<char*>(C) + (size_t)m_main * N * (c_bf16 ? 2 : 4), M - m_main, N, K, epi, tail, st);
+                                     static_cast<char*>(C) + (size_t)m_main * N * (c_bf16 ? 2 : 4), M - m_main, N, K, epi, tail, st,
+                                     true);
     }
     switch (tile) {
         case HMM_GEMM_TILE_SLIVER:     return launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, aux, st);
-        case HMM_GEMM_TILE_128x128_RING: return launch_gemm_small_epi(A, W, bias, C, M, N, K, epi, aux, st);
+        case HMM_GEMM_TILE_128x128_RING: return launch_gemm_ring128_epi(A, W, bias, C, M, N, K, epi, aux, st);
+        case HMM_GEMM_TILE_64x64_RING:   return launch_gemm_ring64_epi(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_256x256_PP: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_128x128:    return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_256x128:    return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);

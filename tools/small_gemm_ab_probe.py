@@ -9,13 +9,14 @@ import torch
 L, lib = load_probe()
 from hippomm_amd.encoder import HipTower, synthetic_state_dict
 
-KNOBS = ("g_gemm_small_stages", "g_enc_sliver_rows")
-configs = [("double_buffer_only", dict(g_gemm_small_stages=2, g_enc_sliver_rows=0)),
-           ("ring4", dict(g_gemm_small_stages=4, g_enc_sliver_rows=0)),
-           ("ring4_sliver_forced", dict(g_gemm_small_stages=4, g_enc_sliver_rows=1 << 30)),
-           ("product", dict(g_gemm_small_stages=4, g_enc_sliver_rows=16448))]
+KNOBS = ("g_gemm_small_stages", "g_enc_sliver_rows", "g_gemm_small_64")
+configs = [("double_buffer_only", dict(g_gemm_small_stages=2, g_enc_sliver_rows=0, g_gemm_small_64=0)),
+           ("ring128", dict(g_gemm_small_stages=4, g_enc_sliver_rows=0, g_gemm_small_64=0)),
+           ("ring64", dict(g_gemm_small_stages=4, g_enc_sliver_rows=0, g_gemm_small_64=512)),
+           ("ring64_sliver_forced", dict(g_gemm_small_stages=4, g_enc_sliver_rows=1 << 30, g_gemm_small_64=512)),
+           ("product", dict(g_gemm_small_stages=4, g_enc_sliver_rows=16448, g_gemm_small_64=512))]
 res = {}
-for kind, batches in (("vision", (256, 96, 64, 48, 32)), ("audio", (128, 32, 16)), ("text", (256, 64))):
+for kind, batches in (("vision", (256, 128, 64, 32, 16)), ("audio", (128, 16)), ("text", (256, 32))):
     tower = HipTower(kind, synthetic_state_dict((kind,), seed=1234))
     torch.cuda.empty_cache()
     for B in batches:
