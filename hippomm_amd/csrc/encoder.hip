@@ -416,12 +416,15 @@ extern "C" double hmm_encoder_flops_executed(const hmm_encoder* e, int batch) {
 namespace hmm {
 HMM_TUNABLE(int, g_enc_cls_fork, 1)      // probe build: 0 = cls-row projection on the chain's own stream (A/B)
 HMM_TUNABLE(int, g_enc_fold_stats, 1)    // probe build: 0 = folded-LayerNorm row statistics by a pass over xb (A/B)
+HMM_TUNABLE(int, g_enc_fused_min_vision, 32) // frames of a forward from which in_proj + attention run as the fused kernel
+HMM_TUNABLE(int, g_enc_fused_min_audio, 6)   // clips (3 per segment) likewise
 HMM_TUNABLE(int, g_enc_sliver_rows, 16448) // token rows of a forward (batch x clips x tokens) up to which few-row GEMMs may use the sliver kernel
 
 struct Chain {                 // one (half-)batch travelling through the tower on one stream
     const void* input; float* out; char* ws; WsPlan p; hipStream_t st; int batch;
     hipStream_t cls_st; hipEvent_t ev_x, ev_cls;      // fork for the cls-row projection of the fused attention path
     int tile;                  // GEMM dispatch of this forward: HMM_GEMM_TILE_AUTO, or AUTO_TILED when the forward is large
+    bool fuse;                 // in_proj + attention as one kernel (large enough forwards only, see hmm_encoder_forward)
 };
 
 #define HMM_TRY(call) do { int _rc = (call); if (_rc != HMM_OK) return _rc; } while (0)
@@ -459,7 +462,7 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
     const int D = e->D, T = e->T, R = p.R, n_img = p.n_img;
     const BlockW& w = e->blocks[i];
     const bool text = e->tower == HMM_TOWER_TEXT;     // the selected (EOS) row differs per sample: no cls-only shortcut
-    const bool fused = e->fused_attention && e->tower == HMM_TOWER_VISION && D == 1280 && e->heads == 16 && T == 257;
+    const bool fused = e->fused_attention && c.fuse && e->tower == HMM_TOWER_VISION && D == 1280 && e->heads == 16 && T == 257;
     if (e->fold_ln && e->tower == HMM_TOWER_VISION && i + 1 < e->depth) {
         // Folded LayerNorm (all blocks but the cls-only last one).  No LayerNorm pass over the residual stream: the
         // residual epilogues (out-proj, fc2) also emit xb = bf16(x) and, per row and 64-column chunk, the chunk statistics of
@@ -535,7 +538,7 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
         HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
         HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, c.tile, st));
         HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, c.tile, st));
-    } else if (i + 1 < e->depth && e->fused_attention && e->tower == HMM_TOWER_AUDIO && D == 768 && e->heads == 12 && T == 229 &&
+    } else if (i + 1 < e->depth && e->fused_attention && c.fuse && e->tower == HMM_TOWER_AUDIO && D == 768 && e->heads == 12 && T == 229 &&
                e->bias_kv) {
         // audio: in_proj + attention in one kernel per (clip, head); every row of a clip fits the 256-row tile, so there is
         // no cls side path.  Bitwise equal to the branch below.
@@ -611,6 +614,10 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
     // the faster kernel on an otherwise idle chip (one question: 3.2 -> 1.3 ms), but next to the big GEMMs of a large batch
     // its unshared L2 reads cost them more than they save (batch 256: +1 %; tools/small_gemm_ab_probe.py).
     const int tile = (int64_t)batch * e->clips * e->T <= g_enc_sliver_rows ? HMM_GEMM_TILE_AUTO : HMM_GEMM_TILE_AUTO_TILED;
+    // The fused in_proj + attention kernel walks one 256 x 256 x D tile per (sample, head): 16 (12) workgroups per frame (clip).
+    // Below ~32 frames that leaves most CUs idle behind a long K walk, and the few-row projection GEMM (64 x 64 tiles behind the
+    // ring) + the attention kernel are faster (1 frame: 3.85 -> 2.60 ms; tools/fused_small_probe.py).  Same bits either way.
+    const bool fuse = batch * e->clips >= (e->tower == HMM_TOWER_VISION ? g_enc_fused_min_vision : g_enc_fused_min_audio);
     Chain chains[2];
     int n_chains = 1;
     int b0 = split_point(e, batch);
@@ -622,13 +629,13 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
         if (cap != hipStreamCaptureStatusNone) b0 = 0;
     }
     if (b0 == 0) {
-        chains[0] = Chain{input_dev, out_dev, ws, ws_plan(e, batch), st, batch, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile};
+        chains[0] = Chain{input_dev, out_dev, ws, ws_plan(e, batch), st, batch, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile, fuse};
     } else {
         const WsPlan p0 = ws_plan(e, b0);
-        chains[0] = Chain{input_dev, out_dev, ws, p0, st, b0, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile};
+        chains[0] = Chain{input_dev, out_dev, ws, p0, st, b0, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile, fuse};
         chains[1] = Chain{static_cast<const char*>(input_dev) + (size_t)b0 * in_bytes_per_sample, out_dev + (size_t)b0 * HMM_FEATURE_DIM,
                           ws + p0.total, ws_plan(e, batch - b0), e->side_stream, batch - b0,
-                          e->cls_stream[1], e->ev_x[1], e->ev_cls[1], tile};
+                          e->cls_stream[1], e->ev_x[1], e->ev_cls[1], tile, fuse};
         n_chains = 2;
         HMM_HIP_CHECK(hipEventRecord(e->ev_fork, st));                       // fork
         HMM_HIP_CHECK(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
