@@ -25,6 +25,8 @@
 namespace hmm {
 
 HMM_TUNABLE(int, g_enc_side_priority, 0) // probe build: HIP priority of the second chain's stream (0 normal, 1 low, -1 high), read at create
+HMM_TUNABLE(int, g_enc_split_min, 64)    // samples x clips of a forward from which it runs as two chains on two streams
+HMM_TUNABLE(int, g_enc_split_min_audio, 12) // the audio tower's smaller kernels overlap from 4 segments on (-7 .. -11 %; tools/split_min_probe.py)
 HMM_TUNABLE(int, g_enc_split_num, 128)   // frames of 256 that go to the first of the two chains
 HMM_TUNABLE(int, g_enc_fold_default, 0)  // 1 = a vision tower starts with LayerNorm folded (hmm_encoder_set_folded_layernorm switches it)
 
@@ -362,7 +364,7 @@ namespace hmm {
 // different CUs.  Measured -4.5 % on the ViT-H forward at batch 256; per-frame results are unchanged
 // (every frame's rows go through the same kernels with the same K order).
 static int split_point(const hmm_encoder* e, int batch) {
-    if (e->streams < 2 || batch * e->clips < 64) return 0;
+    if (e->streams < 2 || batch * e->clips < (e->tower == HMM_TOWER_AUDIO ? g_enc_split_min_audio : g_enc_split_min)) return 0;
     const int b0 = (int)((long)batch * g_enc_split_num / 256);     // probe build: uneven halves (tile-round quantisation A/B)
     return b0 < 1 ? 1 : (b0 >= batch ? batch - 1 : b0);
 }
