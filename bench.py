@@ -22,7 +22,8 @@ so that the random-init tower yields distinct embeddings per scene and the timed
 
 At N = 1 (cfg2) the same JSON line carries the second half of BASELINE's metric under "scan" (the feature_search scan
 over a resident 1M x 1024 fp32 store, k = 32, GB/s of algorithmic bytes), BASELINE cfg 3 under "joint_vision_audio",
-the consolidation timings and the CPU baselines of BASELINE.md section 4.
+the encoder's latency at the reference's own call sizes (32-frame buffer, one frame, one segment, one question) under
+"reference_call_sizes", the consolidation timings and the CPU baselines of BASELINE.md section 4.
 
 roofline      : the dominant kernel of the step (the bf16 GEMM instance with the largest time share),
                 algorithmic FLOPs per launch / mean launch time measured live with HIP events on the
@@ -499,6 +500,43 @@ def joint_bench():
     return out
 
 
+def call_size_bench():
+    """The encoder at the sizes the reference calls it with: the 32-frame buffer of `_process_frame_batch`
+    (hippocampal_memory.py:1328; BASELINE configs[0]), one query frame (:2173), one 10-s audio segment (:1222-1225) and one
+    question (:2173-2176).  Latency-bound launches: wall clock per forward call, outputs left on the device."""
+    from hippomm_amd.encoder import HipTower, synthetic_state_dict
+    out = {"what": "wall-clock ms per forward call at the reference's call sizes (median of 5 x 10 calls after 3 warm-up calls)"}
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for kind, cases in (("vision", (("frames_32", 32), ("frame_1", 1))), ("audio", (("segment_1", 1),)), ("text", (("question_1", 1),))):
+        tower = HipTower(kind, synthetic_state_dict((kind,), seed=1234))
+        for tag, b in cases:
+            if kind == "vision":
+                x = torch.randn(b, 3, 224, 224, device="cuda", generator=gen)
+            elif kind == "audio":
+                x = torch.randn(b, 3, 1, 128, 204, device="cuda", generator=gen)
+            else:
+                x = torch.randint(1, 49000, (b, 77), device="cuda", generator=gen)
+                x[:, 0], x[:, 20] = 49406, 49407
+            emb = torch.empty(b, 1024, device="cuda")
+            for _ in range(3):
+                tower.forward_into(x, emb)
+            torch.cuda.synchronize()
+            t = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    tower.forward_into(x, emb)
+                torch.cuda.synchronize()
+                t.append((time.perf_counter() - t0) / 10 * 1e3)
+            ms = sorted(t)[2]
+            out[f"{kind}_{tag}_ms"] = round(ms, 3)
+            if b > 1:
+                out[f"{kind}_{tag}_per_s"] = round(b / ms * 1e3, 1)
+        del tower
+        torch.cuda.empty_cache()
+    return out
+
+
 def encoder_cpu_baseline(frames32: torch.Tensor):
     """the fp32 oracle tower on this host's cores, batch 32 (processing.frame_buffer_size),
     median of 3 passes."""
@@ -778,6 +816,7 @@ def main():
             if not args.no_scan:
                 line["scan"] = scan_bench(do_cpu=not args.no_cpu_baseline)
                 line["joint_vision_audio"] = joint_bench()
+                line["reference_call_sizes"] = call_size_bench()
                 line["consolidation"] = consolidation_bench(do_cpu=not args.no_cpu_baseline)
             if not args.no_cpu_baseline:
                 line["torch_rocm_reference"] = torch_rocm_reference()
