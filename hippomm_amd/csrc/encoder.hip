@@ -25,7 +25,9 @@
 namespace hmm {
 
 HMM_TUNABLE(int, g_enc_side_priority, 0) // probe build: HIP priority of the second chain's stream (0 normal, 1 low, -1 high), read at create
-HMM_TUNABLE(int, g_enc_split_min, 64)    // samples x clips of a forward from which it runs as two chains on two streams
+HMM_TUNABLE(int, g_enc_split_min, 16)    // frames of a vision forward from which it runs as two chains on two streams (16 .. 56 frames: 0 .. -14 %, except 24: +4 %; tools/mid_batch_probe.py)
+HMM_TUNABLE(int, g_enc_split_min_text, 64)  // the same for the text tower (a wash below 64 questions)
+HMM_TUNABLE(int, g_enc_two_chain_small_tiles, 64)  // gemm_set_small_tiles of a two-chain forward
 HMM_TUNABLE(int, g_enc_split_min_audio, 12) // the audio tower's smaller kernels overlap from 4 segments on (-7 .. -11 %; tools/split_min_probe.py)
 HMM_TUNABLE(int, g_enc_split_num, 128)   // frames of 256 that go to the first of the two chains
 HMM_TUNABLE(int, g_enc_fold_default, 0)  // 1 = a vision tower starts with LayerNorm folded (hmm_encoder_set_folded_layernorm switches it)
@@ -364,7 +366,8 @@ namespace hmm {
 // different CUs.  Measured -4.5 % on the ViT-H forward at batch 256; per-frame results are unchanged
 // (every frame's rows go through the same kernels with the same K order).
 static int split_point(const hmm_encoder* e, int batch) {
-    if (e->streams < 2 || batch * e->clips < (e->tower == HMM_TOWER_AUDIO ? g_enc_split_min_audio : g_enc_split_min)) return 0;
+    const int split_min = e->tower == HMM_TOWER_AUDIO ? g_enc_split_min_audio : e->tower == HMM_TOWER_VISION ? g_enc_split_min : g_enc_split_min_text;
+    if (e->streams < 2 || batch * e->clips < split_min) return 0;
     const int b0 = (int)((long)batch * g_enc_split_num / 256);     // probe build: uneven halves (tile-round quantisation A/B)
     return b0 < 1 ? 1 : (b0 >= batch ? batch - 1 : b0);
 }
@@ -643,11 +646,13 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
         HMM_HIP_CHECK(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
     }
     // launches are interleaved block by block so that both streams always have work queued
+    const int prev_small = gemm_set_small_tiles(n_chains == 2 ? g_enc_two_chain_small_tiles : 128);
     int rc = HMM_OK;
     for (int c = 0; c < n_chains && rc == HMM_OK; ++c) rc = chain_tokens(e, chains[c]);
     for (int i = 0; i < e->depth && rc == HMM_OK; ++i)
         for (int c = 0; c < n_chains && rc == HMM_OK; ++c) rc = chain_block(e, chains[c], i);
     for (int c = 0; c < n_chains && rc == HMM_OK; ++c) rc = chain_head(e, chains[c]);
+    gemm_set_small_tiles(prev_small);
     if (rc != HMM_OK)                                                        // a failed chain may have left its cls fork un-joined
         for (int c = 0; c < 2; ++c) (void)hipStreamSynchronize(e->cls_stream[c]);
     if (n_chains == 2) {

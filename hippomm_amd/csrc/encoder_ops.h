@@ -42,6 +42,10 @@ __device__ __forceinline__ float ln_fold(float acc, float2 rs, float c1, float c
 
 int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int epi,
               int variant, hipStream_t st, const GemmAux* aux = nullptr);
+// Launches of fewer 256x256 tiles than this leave the ping-pong kernel for the small-tile kernels (default 128).  A forward
+// that runs as two chains sets 64 for its duration: its launches share the chip with the other chain's, so half-full
+// ping-pong launches pack well (tools/mid_batch_probe.py).  Per host thread; returns the previous value.
+int gemm_set_small_tiles(int tiles);
 
 int launch_layernorm_bf16(const float* x, size_t in_stride, const float* g, const float* b, bf16_t* y,
                           int rows, int D, float eps, hipStream_t st);

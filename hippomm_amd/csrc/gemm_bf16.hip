@@ -818,6 +818,12 @@ static int launch_gemm_ring128_epi(const bf16_t* A, const bf16_t* W, const float
 // them (64 KiB of LDS, two per CU: ~0.26 us per K-tile, and four times the workgroups of 128x128 tiles); 128x128 tiles behind
 // the ring up to 256 tiles (128 KiB, one per CU); beyond that the double-buffered 128x128 kernel (two per CU).
 HMM_TUNABLE(int, g_gemm_small_stages, 4)   // probe build: 2 = the double-buffered kernel only
+static thread_local int t_gemm_small_tiles = 128;     // see gemm_set_small_tiles (encoder_ops.h)
+int gemm_set_small_tiles(int tiles) {
+    const int prev = t_gemm_small_tiles;
+    t_gemm_small_tiles = tiles;
+    return prev;
+}
 HMM_TUNABLE(int, g_gemm_tail_64, 128)      // the peeled last row tile of a big launch uses 64x64 tiles up to this many of them
 static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                                  int epi, const GemmAux& aux, hipStream_t st, bool tail = false) {
@@ -862,7 +868,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
         const long tiles = (long)tiles_m * tiles_n;
         // few 256x256 tiles (cls-only last block, head): 128x128 tiles put 4x more CUs to work
-        if (tiles < 128)
+        if (tiles < t_gemm_small_tiles)
             return sliver_ok && sliver_wins(M, N, K, epi) ? launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, aux, st)
                                              : launch_gemm_small_epi(A, W, bias, C, M, N, K, epi, aux, st);
         // peel p <= 2 row tiles when that leaves the main launch with a last round that is full or nearly full (>= 240 of 256

@@ -40,5 +40,5 @@ for kind, batches in (("vision", (8, 16, 24, 32, 48, 64, 96)), ("audio", (4, 8, 
             res[m] = (wall_ms(lambda: tower.forward_into(x, out)), out.clone())
             del tower
         print(f"{kind} B={B}: one chain {res[1 << 30][0]:.3f} ms   two chains {res[2][0]:.3f} ms   same bits {torch.equal(res[1 << 30][1], res[2][1])}", flush=True)
-set_min0(64)
+set_min0(16)
 set_min1(12)
