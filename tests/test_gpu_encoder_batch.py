@@ -176,6 +176,40 @@ def test_full_depth_audio_batch128_and_text_batch96_bitwise_batch_invariance():
            what="text full depth B=96")
 
 
+def test_one_sample_at_a_time_equals_the_batch_bitwise():
+    """The reference embeds one question, one query frame, one audio segment at a time.  Those forwards take other kernels than
+    a batch does -- the sliver GEMM and 64x64 tiles behind the LDS-DMA ring instead of the ping-pong kernel, projection GEMM +
+    attention kernel instead of the fused kernel, one chain instead of two -- and must give the same bits as the same sample
+    inside a batch (depth 3; every dispatch boundary is crossed between batch sizes 1, 3 and the whole batch)."""
+    from hippomm_amd.encoder import HipTower
+    spec = ib.reduced(ib.VISION_HUGE, 3)
+    tower = HipTower("vision", ib.synthetic_state(spec, seed=31, init="rich"), depth=3)
+    x = _frames(40, seed=12)
+    whole = tower(x)                                           # two chains of 20, fused attention
+    assert torch.equal(whole, tower(x, max_batch=1))
+    assert torch.equal(whole, tower(x, max_batch=3))
+    assert torch.equal(whole[:17], tower(x[:17]))              # 17 frames: two chains, projection GEMM + attention kernel
+    del tower
+    spec = ib.reduced(ib.AUDIO_HUGE, 3)
+    tower = HipTower("audio", ib.synthetic_state(spec, seed=32, init="rich"), depth=3)
+    mels = torch.randn(9, 3, 1, 128, 204, generator=torch.Generator().manual_seed(13))
+    whole = tower(mels)
+    assert torch.equal(whole, tower(mels, max_batch=1))
+    assert torch.equal(whole, tower(mels, max_batch=2))
+    del tower
+    spec = ib.reduced(ib.TEXT_HUGE, 3)
+    tower = HipTower("text", ib.synthetic_state(spec, seed=33, init="rich"), depth=3)
+    tok = torch.randint(1, 49000, (70, 77), generator=torch.Generator().manual_seed(14))
+    for b in range(70):
+        n = 1 + (b * 11) % 76
+        tok[b, n] = 49407
+        tok[b, n + 1:] = 0
+    whole = tower(tok)                                         # two chains of 35
+    assert torch.equal(whole, tower(tok, max_batch=1))
+    assert torch.equal(whole, tower(tok, max_batch=4))
+    assert torch.equal(whole[:20], tower(tok[:20]))
+
+
 @pytest.mark.parametrize("batch,streams", [(6, 2), (70, 1), (70, 2)])
 def test_forward_is_graph_capturable(batch, streams):
     """include/hippomm_hip.h: every launch goes to the caller's stream and nothing synchronises or allocates, so a forward
