@@ -225,22 +225,41 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = K / 64;
-    auto compute = [&](const char* base) {
+    // All fragment reads of the K-tile first, then the MFMAs in K order behind COUNTED waits: the second half's reads are in
+    // flight under the first half's MFMAs (one exposed LDS latency per K-tile instead of two; with one wave per SIMD nothing else
+    // hides it).  The reads are inline assembly because the compiler waits for lgkmcnt(0) before the first MFMA however the
+    // loads are arranged; the empty asm statements tie each fragment to the wait in front of it (volatile asm keeps its order).
+    const uint32_t lds0 = (uint32_t)(uintptr_t)HMM_LDS_PTR(smem);
+    auto compute = [&](int stage_off) {
+        bf16x8 af[2][MI], wf[2][NI];
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            const int ck = kh ? c_k1 : c_k0;
-            bf16x8 af[MI], wf[NI];
+            const uint32_t pa = lds0 + stage_off + a_off0 + (kh ? c_k1 : c_k0);
+            const uint32_t pw = lds0 + stage_off + w_off0 + (kh ? c_k1 : c_k0);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                af[mi] = *reinterpret_cast<const bf16x8*>(base + a_off0 + mi * 2048 + ck);
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[kh][mi]) : "v"(pa), "n"(mi * 2048));
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                wf[ni] = *reinterpret_cast<const bf16x8*>(base + w_off0 + ni * 2048 + ck);
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[kh][ni]) : "v"(pw), "n"(ni * 2048));
+        }
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            if (kh == 0) {
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MI + NI) : "memory");
+            } else {
+                __builtin_amdgcn_sched_barrier(0);     // the first half's MFMAs stay in front of this wait
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) asm volatile("" : "+v"(af[kh][mi]));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(wf[kh][ni]));
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][ni], af[kh][mi], acc[mi][ni], 0, 0, 0);
         }
     };
     if constexpr (STAGES == 2) {
@@ -250,7 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
         for (int kt = 0; kt < KT; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
-            compute(smem + cur * STAGE);
+            compute(cur * STAGE);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -281,7 +300,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
             __builtin_amdgcn_sched_barrier(0);
             const int nxt = kt + STAGES - 1;
             if (nxt < KT) stage(nxt, buf == 0 ? STAGES - 1 : buf - 1);
-            compute(smem + buf * STAGE);
+            compute(buf * STAGE);
             buf = buf + 1 == STAGES ? 0 : buf + 1;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -722,8 +741,8 @@ static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void
 // (tools/sliver_probe.py, profiles/r3_sliver_probe.json): a wave reads its fragments from L2 unshared, so the kernel moves
 // waves x K x (MT + 1) x 32 B at ~7.5 TB/s chip-wide (less when fewer than ~192 waves are in flight) after ~3 us of launch and
 // first-load latency; 64x64 tiles behind the 4-deep ring -- what a launch this small would otherwise use -- take
-// ~2.8 us + 0.26 us per 64 columns of K.  The sliver kernel wins for one or two dozen rows, and for the text tower's
-// N = 1024 products at 77 rows (out-proj 5.4 vs 6.9 us, fc2 13 vs 20 us).
+// ~2.8 us + 0.225 us per 64 columns of K.  The sliver kernel wins for one or two dozen rows, and for the text tower's
+// N = 1024 products at 77 rows (out-proj 5.4 vs 6.3 us, fc2 13 vs 17 us).
 HMM_TUNABLE(int, g_gemm_sliver_mt, 0)    // probe build: force 16 / 32 / 64 rows per wave (1 / 2 / 4)
 HMM_TUNABLE(int, g_gemm_sliver_auto, 1)  // probe build: 0 = the dispatcher never picks the sliver kernel
 HMM_TUNABLE(int, g_gemm_small_64, 512)   // launches of at most this many 64x64 tiles use them (behind the ring); 0 = never
@@ -742,7 +761,7 @@ static int sliver_mt(int M, int N, int K) {
 static bool sliver_wins(int M, int N, int K, int epi) {
     if (!g_gemm_sliver_auto || epi > HMM_EPI_F32) return false;
     if ((long)((M + 63) / 64) * (N / 64) > 512) return false;               // that many rows: never
-    return sliver_us(M, N, K, sliver_mt(M, N, K)) < 0.85f * (2.8f + 0.26f * (K >> 6));
+    return sliver_us(M, N, K, sliver_mt(M, N, K)) < 0.9f * (2.8f + 0.225f * (K >> 6));
 }
 
 template <int EPI>
@@ -815,7 +834,7 @@ static int launch_gemm_ring128_epi(const bf16_t* A, const bf16_t* W, const float
 
 // Launches of few tiles (small batches, cls rows, the head, the peeled last row tile of the big launches): a workgroup is alone
 // on its CU, so what counts is the latency of its own K walk.  64x64 tiles behind the 4-deep ring while there are at most 512 of
-// them (64 KiB of LDS, two per CU: ~0.26 us per K-tile, and four times the workgroups of 128x128 tiles); 128x128 tiles behind
+// them (64 KiB of LDS, two per CU: ~0.225 us per K-tile, and four times the workgroups of 128x128 tiles); 128x128 tiles behind
 // the ring up to 256 tiles (128 KiB, one per CU); beyond that the double-buffered 128x128 kernel (two per CU).
 HMM_TUNABLE(int, g_gemm_small_stages, 4)   // probe build: 2 = the double-buffered kernel only
 static thread_local int t_gemm_small_tiles = 128;     // see gemm_set_small_tiles (encoder_ops.h)
