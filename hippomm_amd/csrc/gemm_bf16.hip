@@ -14,6 +14,7 @@
 //     stores 8 B (bf16) / 16 B (fp32) per lane instead of 2 B.
 //   - tile order is remapped so that the blocks that land on one XCD (blockIdx % 8) walk
 //     neighbouring tiles and share A / W panels in that XCD's L2.
+#include <type_traits>
 #include "hmm_common.h"
 #include "encoder_ops.h"
 #include "gemm_pp_mainloop.h"
@@ -278,21 +279,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
         // flight), barrier (RAW: every wave's pieces of kt have landed; WAR: every wave has finished reading kt - 1), request
         // K-tile kt + STAGES - 1 into the buffer kt - 1 lived in, compute kt.
         constexpr int PER_STAGE = A_PER_WAVE + W_PER_WAVE;       // LDS-DMA instructions per wave and K-tile
-        static_assert(PER_STAGE * (STAGES - 2) <= 63, "vmcnt is a 6-bit counter");
+        static_assert(STAGES <= 8 && PER_STAGE * (STAGES - 2) <= 63, "vmcnt is a 6-bit counter; the switch below has 7 cases");
 #pragma unroll
         for (int st = 0; st < STAGES - 1; ++st)
             if (st < KT) stage(st, st);
         int buf = 0;
         for (int kt = 0; kt < KT; ++kt) {
-            const int younger = KT - 1 - kt;                     // K-tiles requested after kt so far (at most STAGES - 2)
-            if (younger >= STAGES - 2) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (STAGES - 2)) : "memory");
-            } else if (STAGES > 3 && younger == 1) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
-            } else if (STAGES > 4 && younger == 2) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * 2) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int younger = KT - 1 - kt < STAGES - 2 ? KT - 1 - kt : STAGES - 2;   // K-tiles requested after kt so far
+            switch (younger) {                                   // wave-uniform; the immediate must be a constant
+                case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory"); break;
+                case 2:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * 2) : "memory"); break;
+                case 3:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (STAGES > 4 ? 3 : 0)) : "memory"); break;
+                case 4:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (STAGES > 5 ? 4 : 0)) : "memory"); break;
+                case 5:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (STAGES > 6 ? 5 : 0)) : "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (STAGES > 7 ? 6 : 0)) : "memory"); break;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -809,6 +810,10 @@ static int launch_gemm_epi(const bf16_t* A, const bf16_t* W, const float* bias, 
 #undef HMM_CALL
 }
 
+// 64x64 tiles behind the four-buffer ring (64 KiB of LDS: two workgroups per CU).  Measured and not kept, both bitwise equal:
+// eight buffers (seven K-tiles in flight, one workgroup per CU) 0.29 us per K-tile instead of 0.225; five buffers with the
+// fragments of the next K-tile read under the MFMAs of the current one 0.25 -- the step is the barrier, the DMA issue and the
+// dependent read -> MFMA chain of one wave per SIMD, not bytes in flight.
 static int launch_gemm_ring64_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                                   int epi, const GemmAux& aux, hipStream_t st) {
 #define HMM_CALL(E) launch_gemm<64, 64, 2, 2, E, 4>(A, W, bias, C, M, N, K, aux, st)
