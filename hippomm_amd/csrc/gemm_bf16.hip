@@ -813,7 +813,7 @@ static int launch_gemm_epi(const bf16_t* A, const bf16_t* W, const float* bias, 
 // 64x64 tiles behind the four-buffer ring (64 KiB of LDS: two workgroups per CU).  Measured and not kept, both bitwise equal:
 // eight buffers (seven K-tiles in flight, one workgroup per CU) 0.29 us per K-tile instead of 0.225; five buffers with the
 // fragments of the next K-tile read under the MFMAs of the current one 0.25 -- the step is the barrier, the DMA issue and the
-// dependent read -> MFMA chain of one wave per SIMD, not bytes in flight.
+// dependent read -> MFMA chain, not bytes in flight; eight waves of 32x16 per tile (two per SIMD) 0.25.
 static int launch_gemm_ring64_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                                   int epi, const GemmAux& aux, hipStream_t st) {
 #define HMM_CALL(E) launch_gemm<64, 64, 2, 2, E, 4>(A, W, bias, C, M, N, K, aux, st)
