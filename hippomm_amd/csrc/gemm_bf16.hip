@@ -747,6 +747,8 @@ static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void
 HMM_TUNABLE(int, g_gemm_sliver_mt, 0)    // probe build: force 16 / 32 / 64 rows per wave (1 / 2 / 4)
 HMM_TUNABLE(int, g_gemm_sliver_auto, 1)  // probe build: 0 = the dispatcher never picks the sliver kernel
 HMM_TUNABLE(int, g_gemm_small_64, 512)   // launches of at most this many 64x64 tiles use them (behind the ring); 0 = never
+HMM_TUNABLE(int, g_gemm_small_32, 400)   // launches of at most this many 32x32 tiles use them (behind the ring); 0 = never
+static bool ring32_fits(int M, int N) { return g_gemm_small_32 && (long)((M + 31) / 32) * (N / 32) <= g_gemm_small_32; }
 static float sliver_us(int M, int N, int K, int mt) {
     const long waves = (long)((M + 16 * mt - 1) / (16 * mt)) * (N / 16);
     const float stream = (float)waves * K * (mt + 1) * 32.0f / 7.5e6f;
@@ -762,7 +764,8 @@ static int sliver_mt(int M, int N, int K) {
 static bool sliver_wins(int M, int N, int K, int epi) {
     if (!g_gemm_sliver_auto || epi > HMM_EPI_F32) return false;
     if ((long)((M + 63) / 64) * (N / 64) > 512) return false;               // that many rows: never
-    return sliver_us(M, N, K, sliver_mt(M, N, K)) < 0.9f * (2.8f + 0.225f * (K >> 6));
+    const float per_ktile = ring32_fits(M, N) ? 0.19f : 0.225f;               // what the launch would use instead
+    return sliver_us(M, N, K, sliver_mt(M, N, K)) < 0.9f * (2.8f + per_ktile * (K >> 6));
 }
 
 template <int EPI>
@@ -830,6 +833,20 @@ static int launch_gemm_ring64_epi(const bf16_t* A, const bf16_t* W, const float*
     return HMM_E_INVALID;
 }
 
+static int launch_gemm_ring32_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                                  int epi, const GemmAux& aux, hipStream_t st) {
+#define HMM_CALL(E) launch_gemm<32, 32, 2, 2, E, 4>(A, W, bias, C, M, N, K, aux, st)
+    switch (epi) {
+        case HMM_EPI_BIAS_BF16:      return HMM_CALL(HMM_EPI_BIAS_BF16);
+        case HMM_EPI_BIAS_GELU_BF16: return HMM_CALL(HMM_EPI_BIAS_GELU_BF16);
+        case HMM_EPI_BIAS_RESID_F32: return HMM_CALL(HMM_EPI_BIAS_RESID_F32);
+        case HMM_EPI_F32:            return HMM_CALL(HMM_EPI_F32);
+    }
+#undef HMM_CALL
+    set_error("gemm: 32x32 tiles have no epilogue %d", epi);
+    return HMM_E_INVALID;
+}
+
 static int launch_gemm_ring128_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                                    int epi, const GemmAux& aux, hipStream_t st) {
 #define HMM_CALL(E) launch_gemm<128, 128, 2, 2, E, 4>(A, W, bias, C, M, N, K, aux, st)
@@ -839,7 +856,8 @@ static int launch_gemm_ring128_epi(const bf16_t* A, const bf16_t* W, const float
 
 // Launches of few tiles (small batches, cls rows, the head, the peeled last row tile of the big launches): a workgroup is alone
 // on its CU, so what counts is the latency of its own K walk.  64x64 tiles behind the 4-deep ring while there are at most 512 of
-// them (64 KiB of LDS, two per CU: ~0.225 us per K-tile, and four times the workgroups of 128x128 tiles); 128x128 tiles behind
+// them (64 KiB of LDS, two per CU: ~0.225 us per K-tile, and four times the workgroups of 128x128 tiles), 32x32 tiles (one
+// 16x16 block per wave, ~0.19 us per K-tile) while there are at most 400 of those; 128x128 tiles behind
 // the ring up to 256 tiles (128 KiB, one per CU); beyond that the double-buffered 128x128 kernel (two per CU).
 HMM_TUNABLE(int, g_gemm_small_stages, 4)   // probe build: 2 = the double-buffered kernel only
 static thread_local int t_gemm_small_tiles = 128;     // see gemm_set_small_tiles (encoder_ops.h)
@@ -853,6 +871,7 @@ static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* 
                                  int epi, const GemmAux& aux, hipStream_t st, bool tail = false) {
     if (g_gemm_small_stages == 2 || (long)((M + 127) / 128) * (N / 128) > 256)
         return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
+    if (!tail && epi <= HMM_EPI_F32 && ring32_fits(M, N)) return launch_gemm_ring32_epi(A, W, bias, C, M, N, K, epi, aux, st);
     if (g_gemm_small_64 && epi != HMM_EPI_BIAS_RESID_XB &&
         (long)((M + 63) / 64) * (N / 64) <= (tail ? g_gemm_tail_64 : g_gemm_small_64))
         return launch_gemm_ring64_epi(A, W, bias, C, M, N, K, epi, aux, st);
@@ -922,6 +941,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         case HMM_GEMM_TILE_SLIVER:     return launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_128x128_RING: return launch_gemm_ring128_epi(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_64x64_RING:   return launch_gemm_ring64_epi(A, W, bias, C, M, N, K, epi, aux, st);
+        case HMM_GEMM_TILE_32x32_RING:   return launch_gemm_ring32_epi(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_256x256_PP: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_128x128:    return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
         case HMM_GEMM_TILE_256x128:    return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);

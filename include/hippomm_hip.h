@@ -243,6 +243,7 @@ int hmm_op_gemm_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* 
 #define HMM_GEMM_TILE_SLIVER      5  /* few rows: one wave per 16..64 x 16 sliver, operands from L2 straight into fragments; epilogues 0..3 */
 #define HMM_GEMM_TILE_128x128_RING 6 /* 128x128 tiles behind a 4-deep LDS-DMA ring (counted vmcnt): launches of few tiles, peeled tails */
 #define HMM_GEMM_TILE_64x64_RING  7  /* 64x64 tiles, 4 waves, behind the same ring: more workgroups for mid-size M with a long K */
+#define HMM_GEMM_TILE_32x32_RING  8  /* 32x32 tiles, one 16x16 block per wave, same ring: a few dozen rows x a long K */
 int hmm_op_gemm_bf16_tile(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
                           void* c_dev, int M, int N, int K, int epilogue, int tile, hmm_stream_t stream);
 /* y_bf16[rows, D] = LayerNorm(x_f32[rows, D]) * gamma + beta ; D in {768, 1280} */

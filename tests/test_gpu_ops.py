@@ -32,7 +32,7 @@ def _close_bf16(got, want, extra_atol=0.0):
     assert not bad.any(), f"{int(bad.sum())} / {bad.numel()} off; worst {float((got - want).abs().max()):.4g}"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(257, 1280, 1280), (514, 3840, 1280), (300, 5120, 1280), (257, 1280, 5120),
                                    (1, 1024, 1280), (130, 768, 256), (512, 1280, 640), (1000, 2304, 768)])
 def test_gemm_bias_bf16(variant, M, N, K):
@@ -64,7 +64,7 @@ def test_gemm_epilogues_bitwise_equal_across_tile_geometries():
     for epi, dtype in ((EPI_BIAS_RESID_F32, torch.float32), (EPI_BIAS_GELU_BF16, torch.bfloat16), (EPI_BIAS_BF16, torch.bfloat16),
                        (EPI_F32, torch.float32)):
         outs = []
-        for variant in (0, 1, 2, 3, 4, 5, 6, 7):
+        for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8):
             c = c0.clone().to(dtype)
             L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K, epi, variant,
                                               L.stream_ptr()), "gemm")
@@ -88,7 +88,7 @@ def test_gemm_few_rows_sliver_kernel_bitwise_equal_to_the_tiled_kernels(M, N, K)
     for epi, dtype in ((EPI_BIAS_RESID_F32, torch.float32), (EPI_BIAS_GELU_BF16, torch.bfloat16), (EPI_BIAS_BF16, torch.bfloat16),
                        (EPI_F32, torch.float32)):
         outs = []
-        for variant in (0, 5, -1, 6, 7):
+        for variant in (0, 5, -1, 6, 7, 8):
             c = c0.clone().to(dtype)
             L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K, epi, variant,
                                               L.stream_ptr()), "gemm")
@@ -97,12 +97,13 @@ def test_gemm_few_rows_sliver_kernel_bitwise_equal_to_the_tiled_kernels(M, N, K)
         assert torch.equal(outs[2], outs[0]), f"epilogue {epi}: the default dispatch differs from 128x128 tiles"
         assert torch.equal(outs[3], outs[0]), f"epilogue {epi}: the 4-deep ring differs from the double-buffered 128x128 tiles"
         assert torch.equal(outs[4], outs[0]), f"epilogue {epi}: 64x64 tiles behind the ring differ from 128x128 tiles"
+        assert torch.equal(outs[5], outs[0]), f"epilogue {epi}: 32x32 tiles behind the ring differ from 128x128 tiles"
         assert torch.equal(outs[1][M:], c0[M:].to(dtype)), "rows past M were written"
     want = a.float().cpu() @ w.float().cpu().T + bias.cpu()
     _close_bf16(outs[1][:M], want)                     # the last epilogue of the loop is plain fp32 + bias: a value check on top
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_gelu_resid_f32_epilogues(variant):
     L, lib = _lib()
     M, N, K = 771, 1280, 1280

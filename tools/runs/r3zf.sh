@@ -7,8 +7,8 @@ timeout 600 python sliver_probe.py ../gpurun_out/r3zf/sliver.json > ../gpurun_ou
 python - <<'PY'
 import json
 for r in json.load(open("../gpurun_out/r3zf/sliver.json")):
-    best = min(r["us_128x128_ring4"], r["us_64x64_ring4"], r["us_sliver_16"], r["us_sliver_32"], r["us_sliver_64"], r["us_128x128"])
-    print(r["gemm"], r["M"], "ring128:", r["us_128x128_ring4"], "ring64:", r["us_64x64_ring4"], "auto:", r["us_auto"], "best:", best, "" if r["us_auto"] <= best * 1.08 + 0.3 else "  <-- auto misses")
+    best = min(r["us_128x128_ring4"], r["us_64x64_ring4"], r["us_32x32_ring4"], r["us_sliver_16"], r["us_sliver_32"], r["us_sliver_64"], r["us_128x128"])
+    print(r["gemm"], r["M"], "ring128:", r["us_128x128_ring4"], "ring64:", r["us_64x64_ring4"], "ring32:", r["us_32x32_ring4"], "auto:", r["us_auto"], "best:", best, "" if r["us_auto"] <= best * 1.08 + 0.3 else "  <-- auto misses")
 PY
 grep -i "error\|Traceback" -A 8 ../gpurun_out/r3zf/sliver.log | head -30
 timeout 900 python text_latency_probe.py ../gpurun_out/r3zf/text_latency.json > ../gpurun_out/r3zf/text_latency.log 2>&1

@@ -42,9 +42,11 @@ for name, N, K, epi in SHAPES:
         usa, ca = run(M, N, K, epi, -1)
         usr, cr = run(M, N, K, epi, 6)
         us64, c64 = run(M, N, K, epi, 7)
+        us32, c32 = run(M, N, K, epi, 8)
         rec = {"gemm": name, "M": M, "N": N, "K": K, "us_128x128": round(us0, 1), "us_128x128_ring4": round(usr, 1),
                "ring_same_bits": bool(torch.equal(cr, c0)), "us_64x64_ring4": round(us64, 1),
-               "ring64_same_bits": bool(torch.equal(c64, c0)), "us_auto": round(usa, 1)}
+               "ring64_same_bits": bool(torch.equal(c64, c0)), "us_32x32_ring4": round(us32, 1),
+               "ring32_same_bits": bool(torch.equal(c32, c0)), "us_auto": round(usa, 1)}
         for mt in (1, 2, 4):
             set_mt(mt)
             us, c = run(M, N, K, epi, 5)

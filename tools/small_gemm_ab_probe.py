@@ -9,12 +9,12 @@ import torch
 L, lib = load_probe()
 from hippomm_amd.encoder import HipTower, synthetic_state_dict
 
-KNOBS = ("g_gemm_small_stages", "g_enc_sliver_rows", "g_gemm_small_64")
-configs = [("double_buffer_only", dict(g_gemm_small_stages=2, g_enc_sliver_rows=0, g_gemm_small_64=0)),
-           ("ring128", dict(g_gemm_small_stages=4, g_enc_sliver_rows=0, g_gemm_small_64=0)),
-           ("ring64", dict(g_gemm_small_stages=4, g_enc_sliver_rows=0, g_gemm_small_64=512)),
-           ("ring64_sliver_forced", dict(g_gemm_small_stages=4, g_enc_sliver_rows=1 << 30, g_gemm_small_64=512)),
-           ("product", dict(g_gemm_small_stages=4, g_enc_sliver_rows=16448, g_gemm_small_64=512))]
+KNOBS = ("g_gemm_small_stages", "g_enc_sliver_rows", "g_gemm_small_64", "g_gemm_small_32")
+configs = [("double_buffer_only", dict(g_gemm_small_stages=2, g_enc_sliver_rows=0, g_gemm_small_64=0, g_gemm_small_32=0)),
+           ("ring128", dict(g_gemm_small_stages=4, g_enc_sliver_rows=0, g_gemm_small_64=0, g_gemm_small_32=0)),
+           ("ring64", dict(g_gemm_small_stages=4, g_enc_sliver_rows=0, g_gemm_small_64=512, g_gemm_small_32=0)),
+           ("ring64_sliver_gated", dict(g_gemm_small_stages=4, g_enc_sliver_rows=16448, g_gemm_small_64=512, g_gemm_small_32=0)),
+           ("product", dict(g_gemm_small_stages=4, g_enc_sliver_rows=16448, g_gemm_small_64=512, g_gemm_small_32=400))]
 res = {}
 for kind, batches in (("vision", (256, 128, 64, 32, 16)), ("audio", (128, 16)), ("text", (256, 32))):
     tower = HipTower(kind, synthetic_state_dict((kind,), seed=1234))

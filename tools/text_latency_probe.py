@@ -13,6 +13,7 @@ L, lib = load_probe()
 set_auto = setter(lib, "g_gemm_sliver_auto")
 set_stages = setter(lib, "g_gemm_small_stages")
 set_64 = setter(lib, "g_gemm_small_64")
+set_32 = setter(lib, "g_gemm_small_32")
 from hippomm_amd.encoder import HipTower, synthetic_state_dict   # noqa: E402
 
 rows = []
@@ -54,10 +55,12 @@ for kind, batches in (("text", (1, 2, 3, 4, 8, 16, 64)), ("vision", (1, 2, 4, 8,
             x = torch.randn(B, 3, 224, 224, device="cuda")
         rec = {"tower": kind, "batch": B}
         outs = []
-        for tag, auto, stages, t64 in (("tiled", 0, 2, 0), ("ring128", 0, 4, 0), ("ring64", 0, 4, 512), ("product", 1, 4, 512)):
+        for tag, auto, stages, t64, t32 in (("tiled", 0, 2, 0, 0), ("ring128", 0, 4, 0, 0), ("ring64", 0, 4, 512, 0),
+                                            ("ring64_sliver", 1, 4, 512, 0), ("product", 1, 4, 512, 400)):
             set_auto(auto)
             set_stages(stages)
             set_64(t64)
+            set_32(t32)
             out = torch.empty(B, 1024, device="cuda")
             rec[f"ms_eager_{tag}"] = round(wall_ms(lambda: tower.forward_into(x, out)), 3)
             outs.append(out.clone())
