@@ -741,9 +741,9 @@ static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void
 // Rows per wave of the sliver kernel (16 MT) and whether it beats the tiled kernels, from two fitted lines
 // (tools/sliver_probe.py, profiles/r3_sliver_probe.json): a wave reads its fragments from L2 unshared, so the kernel moves
 // waves x K x (MT + 1) x 32 B at ~7.5 TB/s chip-wide (less when fewer than ~192 waves are in flight) after ~3 us of launch and
-// first-load latency; 64x64 tiles behind the 4-deep ring -- what a launch this small would otherwise use -- take
-// ~2.8 us + 0.225 us per 64 columns of K.  The sliver kernel wins for one or two dozen rows, and for the text tower's
-// N = 1024 products at 77 rows (out-proj 5.4 vs 6.3 us, fc2 13 vs 17 us).
+// first-load latency; tiles behind the 4-deep ring -- what a launch this small would otherwise use -- take ~2.8 us plus
+// 0.225 us (64x64 tiles) or 0.19 us (32x32 tiles, when the launch fits them) per 64 columns of K.  The sliver kernel wins for
+// one or two dozen rows and for the text tower's fc2 at 77 rows (13 vs 15 us).
 HMM_TUNABLE(int, g_gemm_sliver_mt, 0)    // probe build: force 16 / 32 / 64 rows per wave (1 / 2 / 4)
 HMM_TUNABLE(int, g_gemm_sliver_auto, 1)  // probe build: 0 = the dispatcher never picks the sliver kernel
 HMM_TUNABLE(int, g_gemm_small_64, 512)   // launches of at most this many 64x64 tiles use them (behind the ring); 0 = never
