@@ -105,6 +105,7 @@ def launch_ranks(n: int, argv) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.setdefault("NCCL_DEBUG", "VERSION")                  # one stderr line naming the RCCL build the ranks loaded
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -155,6 +156,40 @@ def timed_steps(step, steps: int, warmup: int, sync, barrier, reduce_max):
         last = step()
     sync(); barrier(); sync()
     return reduce_max(time.perf_counter() - t0), last
+
+
+def host_threads() -> int:
+    """THE core count of every CPU baseline in the line: the threads the baseline actually runs on = torch's intra-op pool
+    (physical cores on these hosts; os.cpu_count() counts SMT siblings).  numpy / BLAS legs are pinned to the same number with
+    threadpoolctl, so `cores` means one thing everywhere."""
+    return int(torch.get_num_threads())
+
+
+class blas_threads:
+    """with blas_threads(): numpy's BLAS / OpenMP pools limited to host_threads()."""
+
+    def __enter__(self):
+        try:
+            from threadpoolctl import threadpool_limits
+            self._ctx = threadpool_limits(limits=host_threads())
+            self._ctx.__enter__()
+        except Exception:                                   # noqa: BLE001 - threadpoolctl missing: default pools, still reported
+            self._ctx = None
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+
+def mfma_roofline(flops: float, ms: float, scope: str) -> dict:
+    """Roofline object of a whole forward (scope says what was timed): nominal FLOPs (SURVEY 8d accounting) / wall time against the
+    dense bf16 MFMA peak.  traffic: null (no PMC pass for this workload)."""
+    tf = flops / ms / 1e9
+    return {"bound": "mfma", "scope": scope, "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None, "flops": flops, "ms": round(ms, 4),
+            "flops_accounting": "nominal (reference's un-folded patch conv, every block on every token)"}
 
 
 def event_time_ms(fn, iters, warmup=2):
@@ -341,16 +376,17 @@ def scan_bench(do_cpu):
         idx_gpu, _ = store.search_device(q, SCAN_K)
         host = rows.cpu().numpy()
         qh = q.cpu().numpy()
-        o_idx, _ = top_k_cosine_similarity_oracle(qh, host, SCAN_K)         # warm run (also the parity check)
-        best = 1e9
-        for _ in range(3):
-            t0 = time.perf_counter()
-            top_k_cosine_similarity_oracle(qh, host, SCAN_K)
-            best = min(best, time.perf_counter() - t0)
+        with blas_threads():
+            o_idx, _ = top_k_cosine_similarity_oracle(qh, host, SCAN_K)     # warm run (also the parity check)
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                top_k_cosine_similarity_oracle(qh, host, SCAN_K)
+                best = min(best, time.perf_counter() - t0)
         out["cpu_baseline"] = {"value": round(algo_bytes / best / 1e9, 2), "unit": "GB/s", "s_per_query": round(best, 3),
-                               "cores": os.cpu_count(), "kind": "port",
+                               "cores": host_threads(), "kind": "port",
                                "sample": "numpy oracle (vector_ops.py:151-188 restated) on the full 1M x 1024 store, k=32, "
-                                         "best of 3 after a warm run; numpy/BLAS default threads"}
+                                         f"best of 3 after a warm run; BLAS threads = {host_threads()} (host_threads())"}
         out["parity_vs_oracle"] = {"top32_indices_equal": idx_gpu.cpu().tolist() == [int(i) for i in o_idx]}
         del host
     out["retrieval"] = retrieval_bench(rows, do_cpu)
@@ -422,14 +458,15 @@ def retrieval_bench(rows, do_cpu):
         cos = torch.nn.functional.cosine_similarity(emb.cpu(), ref_q, dim=1)
         qh = q.cpu().numpy()
         host = rows[: 200 * per_event].cpu().numpy()         # the reference's loop on a bounded sample: 200 of the 2000 events
-        t0 = time.perf_counter()
-        hits = [top_k_cosine_similarity_oracle(qh, host[e * per_event:(e + 1) * per_event], 5) for e in range(200)]
-        t_loop = (time.perf_counter() - t0) * (n_events / 200)
+        with blas_threads():
+            t0 = time.perf_counter()
+            hits = [top_k_cosine_similarity_oracle(qh, host[e * per_event:(e + 1) * per_event], 5) for e in range(200)]
+            t_loop = (time.perf_counter() - t0) * (n_events / 200)
         flat = [(float(s), e, int(i)) for e, (idx, sims) in enumerate(hits) for i, s in zip(idx, sims)]
         flat.sort(key=lambda h: -h[0])
         mine = sorted([h for h in _all_hits(events, q) if h[1] < 200], key=lambda h: -h[0])[:5]
         out["cpu_reference"] = {"ms_text_tower_oracle": round(t_tower_cpu * 1e3, 1), "ms_python_loop_all_events": round(t_loop * 1e3, 1),
-                                "cores": os.cpu_count(), "sample": "fp32 oracle text tower, 1 query; numpy scan per event on 200 of the "
+                                "cores": host_threads(), "sample": "fp32 oracle text tower, 1 query; numpy scan per event on 200 of the "
                                 "2000 events, scaled x10"}
         out["parity_vs_oracle"] = {"text_embedding_cos": round(float(cos.min()), 7),
                                    "top5_of_first_200_events_equal": [(e, i) for _, e, i in mine] == [(e, i) for _, e, i in flat[:5]]}
@@ -464,11 +501,13 @@ def consolidation_bench(do_cpu):
             from oracle.consolidation_oracle import select_key_frames_oracle
             want = select_key_frames_oracle(feats, None, 0.9)
             tc = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                select_key_frames_oracle(feats, None, 0.9)
-                tc.append(time.perf_counter() - t0)
+            with blas_threads():
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    select_key_frames_oracle(feats, None, 0.9)
+                    tc.append(time.perf_counter() - t0)
             rec["cpu_ms"] = round(sorted(tc)[1] * 1e3, 3)
+            rec["cpu_cores"] = host_threads()
             rec["kept_equal_oracle"] = kept.cpu().tolist() == want.tolist()
         out[f"n{n}"] = rec
     out["what"] = ("hmm_gram_select vs the numpy oracle (hippocampal_memory.py:944-967 restated) on clustered unit rows; "
@@ -494,7 +533,9 @@ def joint_bench():
     flops = vis.flops(pairs) + aud.flops(pairs)
     out = {"workload": "BASELINE cfg3: 128 frame + 10 s log-mel (3 clips) pairs, vision then audio tower",
            "pairs_per_s": round(pairs / ms * 1e3, 1), "ms": round(ms, 3), "tflops": round(flops / ms / 1e9, 1),
-           "mfma_frac": round(flops / ms / 1e9 / PEAK_BF16_TFLOPS, 4)}
+           "mfma_frac": round(flops / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
+           "tflops_executed": round((vis.flops_executed(pairs) + aud.flops_executed(pairs)) / ms / 1e9, 1),
+           "roofline": mfma_roofline(flops, ms, "vision forward + audio forward of 128 pairs, HIP events on the launch stream")}
     del vis, aud
     torch.cuda.empty_cache()
     return out
@@ -532,6 +573,14 @@ def call_size_bench():
             out[f"{kind}_{tag}_ms"] = round(ms, 3)
             if b > 1:
                 out[f"{kind}_{tag}_per_s"] = round(b / ms * 1e3, 1)
+                out[f"{kind}_{tag}_roofline"] = mfma_roofline(tower.flops(b), ms, f"one forward call of {b} frames, wall clock incl. launch")
+            else:
+                # one sample: the bound is the one read of the tower's bf16 weights from HBM, not the matrix cores
+                wbytes = float(tower.weight_bytes())
+                out[f"{kind}_{tag}_roofline"] = {"bound": "hbm", "scope": "one forward call of 1 sample, wall clock incl. launch",
+                                                 "achieved": round(wbytes / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                 "frac": round(wbytes / ms / 1e6 / PEAK_HBM_GBS, 4), "traffic": None,
+                                                 "algorithmic_bytes": wbytes, "what": "bf16 matrices of every block + head, read once"}
         del tower
         torch.cuda.empty_cache()
     return out
@@ -541,7 +590,7 @@ def encoder_cpu_baseline(frames32: torch.Tensor):
     """the fp32 oracle tower on this host's cores, batch 32 (processing.frame_buffer_size),
     median of 3 passes."""
     from oracle import imagebind_oracle as ib
-    threads = torch.get_num_threads()
+    threads = host_threads()
     st = ib.synthetic_state(ib.VISION_HUGE, seed=1234, init="fast")
     x = frames32.cpu()
     ib.vision_forward(x[:2], st)
@@ -566,8 +615,8 @@ def encoder_parity(tower_sd, frames, emb, rows=(0, 1, 127, 128, 255)):
     got = emb[rows].cpu()
     cos = torch.nn.functional.cosine_similarity(got, want, dim=1)
     return {"rows": rows, "min_cos": round(float(cos.min()), 7), "max_abs_diff": float((got - want).abs().max()),
-            "tolerance": "cos >= 1 - 2e-4 (bf16 operands, fp32 accumulate vs the fp32 oracle)",
-            "ok": bool((1 - cos).max() <= 2e-4)}
+            "tolerance": "cos >= 1 - 5e-5 and max |diff| <= 2e-3 on unit rows (bf16 operands, fp32 accumulate vs the fp32 oracle)",
+            "ok": bool((1 - cos).max() <= 5e-5 and (got - want).abs().max() <= 2e-3)}
 
 
 def torch_rocm_reference():
@@ -587,7 +636,7 @@ def torch_rocm_reference():
     return out
 
 
-def sharded_scan_bench(rank, world, reduce_max, rows_per_gpu=None):
+def sharded_scan_bench(rank, world, reduce_max, rows_per_gpu=None, strong=True):
     """The 1M x 1024 scan at N GPUs (north_star: both metrics at 1 / 2 / 4 / 8 GPUs).  The store is row-sharded
     (hippomm_amd.sharding.sharded_top_k): every rank scans its shard, ONE all-gather of k packed keys (8 k bytes)
     and of the row offsets per query, the same merge on every rank.  Two shapes: 1M rows per GPU (weak; the aggregate
@@ -606,7 +655,8 @@ def sharded_scan_bench(rank, world, reduce_max, rows_per_gpu=None):
         return bool(t.item())
 
     base_rows = rows_per_gpu or SCAN_ROWS                        # tests pass a small store
-    for tag, n_local in (("weak_1M_rows_per_gpu", base_rows), ("strong_1M_rows_total", base_rows // world)):
+    legs = (("weak_1M_rows_per_gpu", base_rows),) + ((("strong_1M_rows_total", base_rows // world),) if strong else ())
+    for tag, n_local in legs:
         rows = store = None
         err = None
         try:
@@ -663,7 +713,12 @@ def main():
     ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scan", action="store_true")
+    ap.add_argument("--cfg5-frames", type=int, default=CFG5_FRAMES,
+                    help="cfg5: frames of the synthetic video (default 3600 = BASELINE cfg 5; other values exercise ragged shards)")
+    ap.add_argument("--scan-strong", action="store_true",
+                    help="N > 1: also time the scan with 1M rows in ALL (strong scaling); default is the weak leg only")
     args = ap.parse_args()
+    t_start = time.perf_counter()
     if args.steps is None:
         args.steps = 10 if args.workload == "cfg2" else 2
     if args.warmup is None:
@@ -707,7 +762,7 @@ def main():
         n_total = FRAMES_PER_GPU * world
         bounds = [(r * FRAMES_PER_GPU, (r + 1) * FRAMES_PER_GPU) for r in range(world)]
     else:
-        n_total = CFG5_FRAMES
+        n_total = args.cfg5_frames
         bounds = shard_bounds(n_total, world)
     lo, hi = bounds[rank]
     counts = [b - a for a, b in bounds]
@@ -729,9 +784,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    startup_s = time.perf_counter() - t_start                  # imports excluded; weights, frames, process group included
     elapsed, (feats, (kept_buf, n_kept)) = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize,
                                                        (dist.barrier if world > 1 else (lambda: None)), reduce_max)
     kept = kept_buf[: int(n_kept.item())].clone()
+    # The timed step is launch-only (selection result left on the device; the last step's list is read after the timer).
+    # Rounds 1-2 read the kept count back inside every step: the same K steps with that read-back, for comparison.
+    def step_with_readback():
+        f, (kb, nk) = step()
+        return f, kb[: int(nk.item())]
+    elapsed_rb, _ = timed_steps(step_with_readback, args.steps, 1, torch.cuda.synchronize,
+                                (dist.barrier if world > 1 else (lambda: None)), reduce_max)
 
     proof = rank_proof(world, rank, local_rank, hi - lo) if world > 1 else None
 
@@ -743,7 +806,7 @@ def main():
             # rank-local failures are agreed on inside (all_ranks_ok) before any collective; what still raises here raises on
             # every rank alike.  Either way the line carries scan.error and the run exits non-zero.
             try:
-                sharded_scan = sharded_scan_bench(rank, world, reduce_max)
+                sharded_scan = sharded_scan_bench(rank, world, reduce_max, strong=args.scan_strong)
             except Exception as exc:                           # noqa: BLE001
                 sharded_scan = {"error": f"{type(exc).__name__}: {exc}"}
 
@@ -761,6 +824,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
             "scaling": "weak" if args.workload == "cfg2" else "strong", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
+            "timed_step": "launch-only: encode -> (all-gather) -> selection, result left on the device, one sync after K steps",
+            "ms_per_step_with_count_readback": round(elapsed_rb / args.steps * 1e3, 3),
+            "value_with_count_readback": round(n_total * args.steps / elapsed_rb, 1),
+            "startup_s": round(startup_s, 2),
         }
         if args.workload == "cfg2":
             line["config"] = {"workload": "BASELINE cfg2: ViT-H/14 vision encoder (32 blocks, 257 tokens, D=1280), 256 "
@@ -772,7 +839,7 @@ def main():
         else:
             from oracle.consolidation_oracle import select_key_frames_oracle
             want = select_key_frames_oracle(feats.cpu().numpy(), None, 0.9)
-            line["config"] = {"workload": "BASELINE cfg5: 1-hour video at 1 fps = 3600 synthetic frames (600 scenes of 6), "
+            line["config"] = {"workload": f"BASELINE cfg5: 1-hour video at 1 fps = {n_total} synthetic frames (scenes of 6), "
                                           "contiguous time shards of ceil(3600/N) frames per rank -> encode -> ONE RCCL "
                                           "all-gather of the (n_local,1024) fp32 embeddings -> global cosine key-frame "
                                           "selection on every rank",
@@ -789,6 +856,12 @@ def main():
             line["rccl_ranks"] = proof["all_reduced_rank_count"] if proof["backend"] == "nccl" else None
             line["collective_backend"] = ("nccl (RCCL)" if proof["backend"] == "nccl" else proof["backend"])
             line["all_reduced_rank_count"] = proof["all_reduced_rank_count"]
+            if proof["backend"] == "nccl":                      # the library behind backend "nccl" on ROCm is RCCL
+                try:
+                    line["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+                except Exception as exc:                        # noqa: BLE001
+                    line["rccl_version"] = f"unavailable: {exc}"
+                line["rccl_env"] = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))}
             line["ranks"] = proof["ranks"]
             n1 = committed_n1_value(args.workload)
             if n1 is not None and not REHEARSAL:
@@ -800,6 +873,10 @@ def main():
         line["flops_per_frame_nominal"] = tower.flops(1)
         line["flops_per_frame_executed"] = round(tower.flops_executed(FRAMES_PER_GPU) / FRAMES_PER_GPU, 1)
         line["step_tflops_executed"] = round(enc_flops_exec * args.steps / elapsed / 1e12, 1)
+        line["step_mfma_frac_executed"] = round(enc_flops_exec * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4)
+        line["step_mfma_frac_note"] = ("step_mfma_frac credits the reference's nominal FLOPs (SURVEY 8d: un-folded patch conv, full last "
+                                       "block); step_mfma_frac_executed counts only what this build runs; roofline.frac is ONE kernel "
+                                       "(the dominant GEMM) on its own 2MNK")
         roof, table = gemm_roofline(FRAMES_PER_GPU)
         line["roofline"], line["kernels"] = roof, table
         if sharded_scan is not None:
@@ -832,7 +909,7 @@ def main():
         if "scan" in line and not line["scan"].get("parity_vs_oracle", {}).get("top32_indices_equal", True):
             bad.append("scan.parity_vs_oracle")
         rp = line.get("scan", {}).get("retrieval", {}).get("parity_vs_oracle")
-        if rp and not (rp["top5_of_first_200_events_equal"] and 1 - rp["text_embedding_cos"] <= 2e-4):
+        if rp and not (rp["top5_of_first_200_events_equal"] and 1 - rp["text_embedding_cos"] <= 5e-5):
             bad.append("scan.retrieval.parity_vs_oracle")
         for tag in ("weak_1M_rows_per_gpu", "strong_1M_rows_total"):
             if "scan" in line and not line["scan"].get(tag, {}).get("indices_match_torch_where_separated", True):

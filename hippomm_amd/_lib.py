@@ -49,19 +49,11 @@ _SIGNATURES = {
     "hmm_encoder_flops_executed": (C.c_double, [c_ptr, C.c_int]),
     "hmm_encoder_set_streams": (C.c_int, [c_ptr, C.c_int]),
     "hmm_encoder_set_fused_attention": (C.c_int, [c_ptr, C.c_int]),
-    "hmm_encoder_set_folded_layernorm": (C.c_int, [c_ptr, C.c_int]),
     "hmm_op_gemm_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     "hmm_op_layernorm_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr]),
     "hmm_op_gemm_bf16_tile": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     "hmm_op_attention_bf16": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr]),
     "hmm_op_qkv_attention_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr]),
-    "hmm_op_rowstat_bf16": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr]),
-    "hmm_op_fold_ln_weights": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
-    "hmm_op_gemm_bf16_ln": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int, c_ptr,
-                                      C.c_int, c_ptr]),
-    "hmm_op_gemm_bf16_resid_xb": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
-    "hmm_op_rowstat_finalize": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr]),
-    "hmm_op_qkv_attention_ln_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr, c_ptr, c_ptr]),
     "hmm_op_qkv_attention_audio_bf16": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr]),
     "hmm_op_attention_causal_bf16": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     "hmm_op_scan_topk_only": (C.c_int, [c_ptr, C.c_int64, c_ptr, C.c_int, c_ptr, c_ptr]),

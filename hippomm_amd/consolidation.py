@@ -4,6 +4,7 @@ bound to ``hmm_gram_select`` (fp32 normalise, fp64-accumulated gram via f64 MFMA
 """
 from __future__ import annotations
 
+import threading
 from typing import Optional, Union
 
 import numpy as np
@@ -14,41 +15,56 @@ from . import _lib
 FEATURE_DIM = 1024
 
 
-_BUFFERS = {}        # (device, n) -> (kept int64[n], n_kept int32[1], workspace): a selection allocates nothing after its first call
+# (device, stream, host thread, n) -> (kept int64[n], n_kept int32[1], workspace): select_key_frames_async allocates nothing
+# after its first call.  The stream and the thread are part of the key: two selections of the same n on different streams or
+# threads never share a workspace.  Only the async entry point uses the cache; the synchronous wrappers own their buffers.
+_BUFFERS = {}
+
+
+def _new_buffers(lib, n, dev):
+    need = lib.hmm_gram_select_workspace_bytes(n)
+    return (torch.empty(max(n, 1), dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
+            torch.empty(max(need, 256), dtype=torch.uint8, device=dev))
+
+
+def _prepare(features: torch.Tensor) -> torch.Tensor:
+    if features.dim() != 2 or features.shape[1] != FEATURE_DIM:
+        raise ValueError(f"features must be (n,{FEATURE_DIM}), got {tuple(features.shape)}")
+    return features if features.dtype == torch.float32 and features.is_contiguous() else features.to(dtype=torch.float32).contiguous()
+
+
+def _launch(lib, f, similarity_threshold, buf):
+    kept, n_kept, ws = buf
+    thr = float(np.float32(similarity_threshold))     # the reference compares in float32 (:960)
+    _lib.check(lib.hmm_gram_select(f.data_ptr(), f.shape[0], FEATURE_DIM, thr, kept.data_ptr(), n_kept.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "hmm_gram_select")
+    return kept, n_kept
 
 
 def select_key_frames_async(features: torch.Tensor, similarity_threshold: float = 0.9):
     """features: (n,1024) fp32 CUDA tensor -> (kept int64[n], n_kept int32[1]) CUDA tensors, WITHOUT synchronising: the
     kept indices are ``kept[:n_kept]`` once the stream has run.  Launch-only (no allocation after the first call for a
-    given n, no read-back); the two tensors are reused by the next call with the same n on the same device, so consume
-    or copy them before that."""
+    given n on this stream and thread, no read-back); the two tensors are reused by the next such call, so consume or copy
+    them before that."""
     lib = _lib.load()
-    if features.dim() != 2 or features.shape[1] != FEATURE_DIM:
-        raise ValueError(f"features must be (n,{FEATURE_DIM}), got {tuple(features.shape)}")
-    f = features if features.dtype == torch.float32 and features.is_contiguous() else features.to(dtype=torch.float32).contiguous()
-    n = f.shape[0]
-    dev = f.device
-    key = (dev.index, n)
+    f = _prepare(features)
+    n, dev = f.shape[0], f.device
+    key = (dev.index, int(_lib.stream_ptr().value or 0), threading.get_ident(), n)
     buf = _BUFFERS.get(key)
     if buf is None:
         if len(_BUFFERS) >= 16:                             # a handful of sizes recur (frame buffer, per-video totals)
             _BUFFERS.pop(next(iter(_BUFFERS)))
-        need = lib.hmm_gram_select_workspace_bytes(n)
-        buf = (torch.empty(max(n, 1), dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
-               torch.empty(max(need, 256), dtype=torch.uint8, device=dev))
-        _BUFFERS[key] = buf
-    kept, n_kept, ws = buf
-    thr = float(np.float32(similarity_threshold))     # the reference compares in float32 (:960)
-    _lib.check(lib.hmm_gram_select(f.data_ptr(), n, FEATURE_DIM, thr, kept.data_ptr(), n_kept.data_ptr(),
-                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "hmm_gram_select")
-    return kept, n_kept
+        buf = _BUFFERS[key] = _new_buffers(lib, n, dev)
+    return _launch(lib, f, similarity_threshold, buf)
 
 
 def select_key_frames_device(features: torch.Tensor, similarity_threshold: float = 0.9) -> torch.Tensor:
-    """features: (n,1024) fp32 CUDA tensor -> kept indices int64 CUDA tensor (synchronises once to read the count; the
-    result is the caller's own tensor)."""
-    kept, n_kept = select_key_frames_async(features, similarity_threshold)
-    return kept[: int(n_kept.item())].clone()
+    """features: (n,1024) fp32 CUDA tensor -> kept indices int64 CUDA tensor (synchronises once to read the count; buffers
+    and result are this call's own)."""
+    lib = _lib.load()
+    f = _prepare(features)
+    kept, n_kept = _launch(lib, f, similarity_threshold, _new_buffers(lib, f.shape[0], f.device))
+    return kept[: int(n_kept.item())]
 
 
 def select_key_frames(features: Union[np.ndarray, torch.Tensor], times: Optional[np.ndarray] = None,

@@ -30,7 +30,6 @@ HMM_TUNABLE(int, g_enc_split_min_text, 64)  // the same for the text tower (a wa
 HMM_TUNABLE(int, g_enc_two_chain_small_tiles, 64)  // gemm_set_small_tiles of a two-chain forward
 HMM_TUNABLE(int, g_enc_split_min_audio, 12) // the audio tower's smaller kernels overlap from 4 segments on (-7 .. -11 %; tools/split_min_probe.py)
 HMM_TUNABLE(int, g_enc_split_num, 128)   // frames of 256 that go to the first of the two chains
-HMM_TUNABLE(int, g_enc_fold_default, 0)  // 1 = a vision tower starts with LayerNorm folded (hmm_encoder_set_folded_layernorm switches it)
 
 enum PackKind { PACK_F32, PACK_BF16, PACK_FOLD_CONV3D };
 
@@ -39,24 +38,11 @@ struct ParamSlot {
     int64_t numel_src;  // elements the caller must provide
     PackKind kind;
     bool loaded;
-    int fold_block = -1;   // folded LayerNorm (vision): block and role of this parameter in a fold group, see FoldBit
-    int fold_bit = 0;
-    size_t fold_src = 0;   // fp32 copy of a weight matrix in the fold staging buffer, until its group is folded
 };
-
-// A LayerNorm and the Linear behind it are folded into (wf, c1, c2) as soon as their four parameters have arrived
-// (launch_fold_ln_weights); group 0 = norm_1 + attn.in_proj, group 1 = norm_2 + mlp.fc1.
-enum FoldBit { FOLD_G = 1, FOLD_B = 2, FOLD_W = 4, FOLD_BIAS = 8, FOLD_ALL = 15 };
 
 struct BlockW {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *qkv_b, *out_b, *fc1_b, *fc2_b, *bias_k, *bias_v;
     bf16_t *qkv_w, *out_w, *fc1_w, *fc2_w;
-    // folded LayerNorm: wf = bf16(gamma (.) w), c1 = row sums of wf, c2 = w beta + bias  (group 0: qkv, group 1: fc1)
-    bf16_t* wf[2] = {nullptr, nullptr};
-    float *c1[2] = {nullptr, nullptr}, *c2[2] = {nullptr, nullptr};
-    float* w_src[2] = {nullptr, nullptr};    // fp32 staging copies (fold_stage)
-    int have[2] = {0, 0};
-    bool folded[2] = {false, false};
 };
 
 }  // namespace hmm
@@ -70,9 +56,6 @@ struct hmm_encoder {
     int device = 0;                         // the device the handle was created on (weights, side stream, events)
     int streams = 2;                        // 2: half-batches on two streams (default), 1: one chain (hmm_encoder_set_streams)
     bool fused_attention = true;            // vision tower: in_proj + attention as one kernel (hmm_encoder_set_fused_attention)
-    bool fold_ln = false;                   // vision tower: LayerNorm folded into the neighbouring GEMMs (hmm_encoder_set_folded_layernorm)
-    char* fold_stage = nullptr;             // fp32 copies of in_proj / fc1 weights until their LayerNorm has arrived
-    size_t fold_stage_bytes = 0;
     hipStream_t side_stream = nullptr;      // second half-batch runs here (see hmm_encoder_forward)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t cls_stream[2] = {nullptr, nullptr};   // per chain: the cls-row projection of the fused attention path
@@ -135,12 +118,6 @@ static void plan_params(hmm_encoder* e, std::vector<std::pair<void**, size_t>>& 
         f32(tr + "pre_transformer_layer.0.bias", D, &e->pre_b);
     }
     e->blocks.resize(e->depth);
-    const bool fold = e->tower == HMM_TOWER_VISION;
-    size_t stage = 0;
-    auto mark = [&](const std::string& key, int block, int bit) {
-        ParamSlot& sl = e->slots[key];
-        sl.fold_block = block; sl.fold_bit = bit;
-    };
     for (int i = 0; i < e->depth; ++i) {
         const std::string b = tr + "blocks." + std::to_string(i) + ".";
         BlockW& w = e->blocks[i];
@@ -162,24 +139,7 @@ static void plan_params(hmm_encoder* e, std::vector<std::pair<void**, size_t>>& 
         f32(b + "mlp.fc1.bias", e->mlp, &w.fc1_b);
         b16(b + "mlp.fc2.weight", (int64_t)D * e->mlp, &w.fc2_w);
         f32(b + "mlp.fc2.bias", D, &w.fc2_b);
-        if (fold && i + 1 < e->depth) {                 // the last block runs on the cls rows only: plain LayerNorm there
-            const int rows[2] = {3 * D, e->mlp};
-            const std::string keys[2][4] = {{b + "norm_1.weight", b + "norm_1.bias", b + "attn.in_proj_weight", b + "attn.in_proj_bias"},
-                                            {b + "norm_2.weight", b + "norm_2.bias", b + "mlp.fc1.weight", b + "mlp.fc1.bias"}};
-            for (int g = 0; g < 2; ++g) {
-                for (int k = 0; k < 4; ++k) mark(keys[g][k], i * 2 + g, 1 << k);
-                e->slots[keys[g][2]].fold_src = stage;
-                stage = align_up(stage + (size_t)rows[g] * D * 4, 256);
-                fix.push_back({reinterpret_cast<void**>(&w.wf[g]), ab.cursor});
-                ab.cursor = align_up(ab.cursor + (size_t)rows[g] * D * 2, 256);
-                fix.push_back({reinterpret_cast<void**>(&w.c1[g]), ab.cursor});
-                ab.cursor = align_up(ab.cursor + (size_t)rows[g] * 4, 256);
-                fix.push_back({reinterpret_cast<void**>(&w.c2[g]), ab.cursor});
-                ab.cursor = align_up(ab.cursor + (size_t)rows[g] * 4, 256);
-            }
-        }
     }
-    e->fold_stage_bytes = stage;
     if (e->tower == HMM_TOWER_TEXT) {
         f32(hd + "proj.0.weight", D, &e->head_g);
         f32(hd + "proj.0.bias", D, &e->head_b);
@@ -193,7 +153,7 @@ static void plan_params(hmm_encoder* e, std::vector<std::pair<void**, size_t>>& 
     e->arena_bytes = ab.cursor;
 }
 
-struct WsPlan { int n_img, R; size_t off_x, off_a, off_big, off_im2col, off_patch, off_hl, off_hv, off_xc, off_ac, off_qc, off_hc, off_sel, off_xb, off_rs, off_part, total; };
+struct WsPlan { int n_img, R; size_t off_x, off_a, off_big, off_im2col, off_patch, off_hl, off_hv, off_xc, off_ac, off_qc, off_hc, off_sel, total; };
 
 static WsPlan ws_plan(const hmm_encoder* e, int batch) {
     WsPlan p{};
@@ -218,13 +178,6 @@ static WsPlan ws_plan(const hmm_encoder* e, int batch) {
     p.off_qc = cur;  cur = align_up(cur + (size_t)p.n_img * D * 2, 256);
     p.off_hc = cur;  cur = align_up(cur + (size_t)p.n_img * e->mlp * 2, 256);
     p.off_sel = cur; cur = align_up(cur + (size_t)p.n_img * 4, 256);
-    // folded LayerNorm (vision): the bf16 image of the residual stream and its row statistics
-    p.off_xb = p.off_rs = p.off_part = cur;
-    if (e->tower == HMM_TOWER_VISION) {
-        p.off_xb = cur;   cur = align_up(cur + (size_t)p.R * D * 2, 256);
-        p.off_rs = cur;   cur = align_up(cur + (size_t)p.R * 8, 256);
-        p.off_part = cur; cur = align_up(cur + (size_t)p.R * (D / 64) * 8, 256);
-    }
     p.total = cur + 256;
     return p;
 }
@@ -259,7 +212,6 @@ extern "C" int hmm_encoder_create(hmm_encoder** out, int tower, int depth) {
     plan_params(e, fix);
     hipError_t err = hipGetDevice(&e->device);
     if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->arena), e->arena_bytes);
-    if (err == hipSuccess && e->fold_stage_bytes) err = hipMalloc(reinterpret_cast<void**>(&e->fold_stage), e->fold_stage_bytes);
     // the side stream and its fork/join events belong to the handle's device and exist before the first forward,
     // so that hmm_encoder_forward creates nothing (graph capture) and never lands them on another current device
     if (err == hipSuccess) err = g_enc_side_priority == 0 ? hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking)
@@ -285,7 +237,6 @@ extern "C" int hmm_encoder_create(hmm_encoder** out, int tower, int depth) {
 extern "C" void hmm_encoder_destroy(hmm_encoder* e) {
     if (!e) return;
     if (e->arena) (void)hipFree(e->arena);
-    if (e->fold_stage) (void)hipFree(e->fold_stage);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
@@ -315,26 +266,6 @@ extern "C" int hmm_encoder_load_param(hmm_encoder* e, const char* key, const flo
     }
     if (rc != HMM_OK) return rc;
     s.loaded = true;
-    if (s.fold_block >= 0) {
-        // Folded LayerNorm: keep an fp32 copy of the weight matrix until gamma / beta / bias are there too, then build
-        // (wf, c1, c2) on this stream -- parameters are expected on ONE stream, in any order.
-        BlockW& w = e->blocks[s.fold_block >> 1];
-        const int g = s.fold_block & 1;
-        HMM_REQUIRE(e->fold_stage != nullptr, HMM_E_INVALID, "encoder_load_param: '%s' reloaded after the fold staging buffer was released", key);
-        if (s.fold_bit == FOLD_W) {
-            w.w_src[g] = reinterpret_cast<float*>(e->fold_stage + s.fold_src);
-            rc = launch_copy_f32(data_dev, w.w_src[g], numel, st);
-            if (rc != HMM_OK) return rc;
-        }
-        w.have[g] |= s.fold_bit;
-        if (w.have[g] == FOLD_ALL) {
-            const int rows = g == 0 ? 3 * e->D : e->mlp;
-            rc = launch_fold_ln_weights(w.w_src[g], g == 0 ? w.ln1_g : w.ln2_g, g == 0 ? w.ln1_b : w.ln2_b,
-                                        g == 0 ? w.qkv_b : w.fc1_b, w.wf[g], w.c1[g], w.c2[g], rows, e->D, st);
-            if (rc != HMM_OK) return rc;
-            w.folded[g] = true;
-        }
-    }
     return HMM_OK;
 }
 
@@ -348,15 +279,6 @@ extern "C" int hmm_encoder_missing_params(hmm_encoder* e) {
             ++missing;
         }
     if (missing) set_error("%d parameter(s) not loaded: %s%s", missing, names.c_str(), missing > 8 ? ", ..." : "");
-    if (missing == 0 && e->fold_stage) {                 // every fold group is built: the fp32 staging copies can go
-        bool all = true;
-        for (int i = 0; i + 1 < e->depth; ++i) all = all && e->blocks[i].folded[0] && e->blocks[i].folded[1];
-        if (all) {
-            (void)hipFree(e->fold_stage);               // synchronises the device: the fold kernels are done
-            e->fold_stage = nullptr;
-            e->fold_ln = g_enc_fold_default != 0;       // built and parity-tested, but not faster: opt-in
-        }
-    }
     return missing;
 }
 
@@ -380,18 +302,6 @@ extern "C" size_t hmm_encoder_workspace_bytes(const hmm_encoder* e, int batch) {
     if (b0 == 0) return one;
     const size_t two = ws_plan(e, b0).total + ws_plan(e, batch - b0).total;
     return two > one ? two : one;            // a forward under stream capture runs as one chain (see hmm_encoder_forward)
-}
-
-extern "C" int hmm_encoder_set_folded_layernorm(hmm_encoder* e, int on) {
-    HMM_REQUIRE(e, HMM_E_INVALID, "encoder_set_folded_layernorm: null handle");
-    if (on) {
-        HMM_REQUIRE(e->tower == HMM_TOWER_VISION, HMM_E_INVALID, "encoder_set_folded_layernorm: vision tower only");
-        for (int i = 0; i + 1 < e->depth; ++i)
-            HMM_REQUIRE(e->blocks[i].folded[0] && e->blocks[i].folded[1], HMM_E_INVALID,
-                        "encoder_set_folded_layernorm: block %d is not folded yet (load every parameter first)", i);
-    }
-    e->fold_ln = on != 0;
-    return HMM_OK;
 }
 
 extern "C" double hmm_encoder_flops(const hmm_encoder* e, int batch) {
@@ -420,7 +330,6 @@ extern "C" double hmm_encoder_flops_executed(const hmm_encoder* e, int batch) {
 
 namespace hmm {
 HMM_TUNABLE(int, g_enc_cls_fork, 1)      // probe build: 0 = cls-row projection on the chain's own stream (A/B)
-HMM_TUNABLE(int, g_enc_fold_stats, 1)    // probe build: 0 = folded-LayerNorm row statistics by a pass over xb (A/B)
 HMM_TUNABLE(int, g_enc_fused_min_vision, 32) // frames of a forward from which in_proj + attention run as the fused kernel
 HMM_TUNABLE(int, g_enc_fused_min_audio, 6)   // clips (3 per segment) likewise
 HMM_TUNABLE(int, g_enc_sliver_rows, 16448) // token rows of a forward (batch x clips x tokens) up to which few-row GEMMs may use the sliver kernel
@@ -468,59 +377,6 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
     const BlockW& w = e->blocks[i];
     const bool text = e->tower == HMM_TOWER_TEXT;     // the selected (EOS) row differs per sample: no cls-only shortcut
     const bool fused = e->fused_attention && c.fuse && e->tower == HMM_TOWER_VISION && D == 1280 && e->heads == 16 && T == 257;
-    if (e->fold_ln && e->tower == HMM_TOWER_VISION && i + 1 < e->depth) {
-        // Folded LayerNorm (all blocks but the cls-only last one).  No LayerNorm pass over the residual stream: the
-        // residual epilogues (out-proj, fc2) also emit xb = bf16(x) and, per row and 64-column chunk, the chunk statistics of
-        // what they stored; a row-per-thread kernel combines a row's 20 chunks into (rstd, rstd * mean) (10 MB instead of
-        // a 168-MB pass over xb); the consumers (in_proj, fc1) multiply xb by wf = bf16(gamma (.) W) and finish LayerNorm
-        // in their epilogue (encoder_ops.h: ln_fold).  Per norm 505 MB of LayerNorm traffic become the 168-MB xb store.
-        // LN(x) is applied to bf16(x) instead of being rounded after the normalisation: one activation rounding either
-        // way; rows whose mean is many standard deviations lose precision to the cancellation of the mean term
-        // (DESIGN.md 4.5).  Block 0 takes xb and its statistics from the assembled tokens with two small passes.
-        bf16_t* xb = reinterpret_cast<bf16_t*>(c.ws + p.off_xb);
-        float2* rs = reinterpret_cast<float2*>(c.ws + p.off_rs);
-        float2* part = reinterpret_cast<float2*>(c.ws + p.off_part);
-        const bool in_epi = g_enc_fold_stats != 0;               // probe build: 0 = statistics by a pass over xb (A/B)
-        GemmAux emit; emit.xb = xb; emit.part = in_epi ? part : nullptr;
-        GemmAux ln0; ln0.rs = rs; ln0.c1 = w.c1[0];
-        GemmAux ln1; ln1.rs = rs; ln1.c1 = w.c1[1];
-        auto stats = [&]() -> int {                              // rs of the xb rows the last residual GEMM wrote
-            return in_epi ? launch_rowstat_finalize(part, rs, R, D, 1e-6f, st) : launch_rowstat_bf16(xb, rs, R, D, 1e-6f, st);
-        };
-        if (i == 0) {                                            // later: written by the previous block's fc2
-            HMM_TRY(launch_cast_bf16(x, xb, (int64_t)R * D, st));
-            HMM_TRY(launch_rowstat_bf16(xb, rs, R, D, 1e-6f, st));
-        }
-        if (fused) {
-            // the cls rows (token 0 of every image) do not fit the fused kernel's 256-row tile: their q | k | v come from a
-            // small GEMM on a forked stream (their statistics are rows b * T of rs)
-            hipStream_t cst = g_enc_cls_fork ? c.cls_st : st;
-            if (g_enc_cls_fork) {
-                HMM_HIP_CHECK(hipEventRecord(c.ev_x, st));                    // xb and rs of this block are final on `st`
-                HMM_HIP_CHECK(hipStreamWaitEvent(cst, c.ev_x, 0));
-            }
-            HMM_TRY(launch_gather_rows(xb, (size_t)T * D * 2, ac, n_img, D * 2, cst));
-            GemmAux lc; lc.rs = rs; lc.rs_stride = T; lc.c1 = w.c1[0];
-            HMM_TRY(gemm_bf16(ac, w.wf[0], w.c2[0], hc, n_img, 3 * D, D, HMM_EPI_LN_BF16, c.tile, cst, &lc));
-            if (g_enc_cls_fork) {
-                HMM_HIP_CHECK(hipEventRecord(c.ev_cls, cst));
-                HMM_HIP_CHECK(hipStreamWaitEvent(st, c.ev_cls, 0));
-            }
-            HMM_TRY(qkv_attention_bf16(xb, w.wf[0], w.c2[0], hc, big, n_img, st, rs, w.c1[0]));
-            HMM_TRY(gemm_bf16(big, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_XB, c.tile, st, &emit));
-        } else {
-            HMM_TRY(gemm_bf16(xb, w.wf[0], w.c2[0], big, R, 3 * D, D, HMM_EPI_LN_BF16, c.tile, st, &ln0));
-            HMM_TRY(attention_bf16(big, a, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st, false));
-            HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_XB, c.tile, st, &emit));
-        }
-        HMM_TRY(stats());
-        HMM_TRY(gemm_bf16(xb, w.wf[1], w.c2[1], big, R, e->mlp, D, HMM_EPI_LN_GELU_BF16, c.tile, st, &ln1));
-        const bool next_folded = i + 2 < e->depth;
-        HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, next_folded ? HMM_EPI_BIAS_RESID_XB : HMM_EPI_BIAS_RESID_F32,
-                          c.tile, st, &emit));
-        if (next_folded) HMM_TRY(stats());
-        return HMM_OK;
-    }
     if (!(i + 1 < e->depth && fused)) HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
     if (i + 1 < e->depth && fused) {
         // in_proj + attention in one kernel per (image, head): the packed qkv matrix never exists in HBM.  The cls rows

@@ -258,88 +258,6 @@ __global__ void fold_conv3d_kernel(const float* __restrict__ w, bf16_t* __restri
 }
 
 // ---- launchers ------------------------------------------------------------------------------
-// ---- folded LayerNorm (vision tower): row statistics of the bf16 residual image, and the one-off weight fold -------------
-// rs[r] = (rstd, rstd * mean) of row r of xb, two passes over the row held in registers (one wave per row), so that a
-// consumer GEMM on W' = bf16(gamma (.) W) can apply  rstd * acc - rstd * mean * sum_k W'  in its epilogue (encoder_ops.h).
-// The statistics are those of the bf16 values that enter the product: the mean term cancels exactly.
-template <int CHUNKS>
-__global__ __launch_bounds__(256) void rowstat_bf16_kernel(const bf16_t* __restrict__ xb, float2* __restrict__ rs, int rows, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    constexpr int D = CHUNKS * 256;
-    const bf16x4* p = reinterpret_cast<const bf16x4*>(xb + (size_t)row * D) + lane;
-    float v[CHUNKS * 4];
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < CHUNKS; ++c) {
-        const bf16x4 t = p[c * 64];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[c * 4 + j] = (float)t[j]; s += v[c * 4 + j]; }
-    }
-    const float mean = wave_sum(s) * (1.0f / D);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < CHUNKS * 4; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
-    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
-    if (lane == 0) rs[row] = make_float2(rstd, rstd * mean);
-}
-
-// rs[r] = (rstd, rstd * mean) of row r from the per-chunk statistics the RESID_XB epilogues emitted (encoder_ops.h):
-// part[r][c] = (sum, sum of squares about the chunk mean) of columns 64 c .. 64 c + 63.  Chunks are combined in chunk order:
-// mean = (sum_c s_c) / D,  M2 = sum_c (q_c + 64 (s_c / 64 - mean)^2)  (Chan et al.), rstd = rsqrt(M2 / D + eps).
-template <int CHUNKS>
-__global__ __launch_bounds__(256) void rowstat_finalize_kernel(const float2* __restrict__ part, float2* __restrict__ rs, int rows,
-                                                               float eps) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= rows) return;
-    static_assert(CHUNKS % 2 == 0, "two chunks per 16-byte load");
-    const float4* p = reinterpret_cast<const float4*>(part + (size_t)row * CHUNKS);
-    float4 v[CHUNKS / 2];
-#pragma unroll
-    for (int c = 0; c < CHUNKS / 2; ++c) v[c] = p[c];
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < CHUNKS / 2; ++c) { s += v[c].x; s += v[c].z; }
-    constexpr float inv_d = 1.0f / (64.0f * CHUNKS);
-    const float mean = s * inv_d;
-    float m2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < CHUNKS / 2; ++c) {
-        const float d0 = v[c].x * (1.0f / 64.0f) - mean, d1 = v[c].z * (1.0f / 64.0f) - mean;
-        m2 += fmaf(64.0f * d0, d0, v[c].y);
-        m2 += fmaf(64.0f * d1, d1, v[c].w);
-    }
-    const float rstd = rsqrtf(m2 * inv_d + eps);
-    rs[row] = make_float2(rstd, rstd * mean);
-}
-
-// One workgroup per output row n of a Linear that follows a LayerNorm:  wf[n][k] = bf16(gamma[k] * w0[n][k]),
-// c1[n] = sum_k wf[n][k] (of the ROUNDED values: it multiplies the same mean the product sees),
-// c2[n] = sum_k w0[n][k] * beta[k] + bias[n].  fp64 sums, fixed reduction order.
-__global__ __launch_bounds__(256) void fold_ln_weights_kernel(const float* __restrict__ w0, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, const float* __restrict__ bias,
-                                                              bf16_t* __restrict__ wf, float* __restrict__ c1,
-                                                              float* __restrict__ c2, int D) {
-    __shared__ double red[2][256];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    double a1 = 0.0, a2 = 0.0;
-    for (int k = tid; k < D; k += 256) {
-        const float w = w0[(size_t)n * D + k];
-        const bf16_t r = (bf16_t)(w * gamma[k]);
-        wf[(size_t)n * D + k] = r;
-        a1 += (double)(float)r;
-        a2 += (double)w * (double)beta[k];
-    }
-    red[0][tid] = a1; red[1][tid] = a2;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
-        if (tid < h) { red[0][tid] += red[0][tid + h]; red[1][tid] += red[1][tid + h]; }
-        __syncthreads();
-    }
-    if (tid == 0) { c1[n] = (float)red[0][0]; c2[n] = (float)(red[1][0] + (double)bias[n]); }
-}
-
 HMM_TUNABLE(int, g_ln_nt_loads, 1)       // non-temporal loads of the fp32 residual stream in LayerNorm (read once; keeps the bf16 output cache-resident for its consumer: forward -0.9 %, profiles/r3_forward_ab.json); probe build: A/B
 
 int launch_layernorm_bf16(const float* x, size_t in_stride, const float* g, const float* b, bf16_t* y,
@@ -410,30 +328,6 @@ int launch_gather_selected_rows(const void* src, const int32_t* sel, int T, void
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
-int launch_rowstat_bf16(const bf16_t* xb, float2* rs, int rows, int D, float eps, hipStream_t st) {
-    HMM_REQUIRE(D == 1280 || D == 768 || D == 1024, HMM_E_INVALID, "rowstat: unsupported width %d", D);
-    const unsigned grid = (unsigned)((rows + 3) / 4);
-    if (D == 1280)      rowstat_bf16_kernel<5><<<grid, 256, 0, st>>>(xb, rs, rows, eps);
-    else if (D == 1024) rowstat_bf16_kernel<4><<<grid, 256, 0, st>>>(xb, rs, rows, eps);
-    else                rowstat_bf16_kernel<3><<<grid, 256, 0, st>>>(xb, rs, rows, eps);
-    HMM_LAUNCH_CHECK();
-    return HMM_OK;
-}
-int launch_rowstat_finalize(const float2* part, float2* rs, int rows, int D, float eps, hipStream_t st) {
-    HMM_REQUIRE(D == 1280 || D == 768 || D == 1024, HMM_E_INVALID, "rowstat_finalize: unsupported width %d", D);
-    const unsigned grid = (unsigned)((rows + 255) / 256);
-    if (D == 1280)      rowstat_finalize_kernel<20><<<grid, 256, 0, st>>>(part, rs, rows, eps);
-    else if (D == 1024) rowstat_finalize_kernel<16><<<grid, 256, 0, st>>>(part, rs, rows, eps);
-    else                rowstat_finalize_kernel<12><<<grid, 256, 0, st>>>(part, rs, rows, eps);
-    HMM_LAUNCH_CHECK();
-    return HMM_OK;
-}
-int launch_fold_ln_weights(const float* w0, const float* gamma, const float* beta, const float* bias, bf16_t* wf,
-                           float* c1, float* c2, int N, int D, hipStream_t st) {
-    fold_ln_weights_kernel<<<N, 256, 0, st>>>(w0, gamma, beta, bias, wf, c1, c2, D);
-    HMM_LAUNCH_CHECK();
-    return HMM_OK;
-}
 int launch_cast_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t st) {
     cast_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(src, dst, n);
     HMM_LAUNCH_CHECK();
@@ -454,26 +348,6 @@ int launch_fold_conv3d(const float* w, bf16_t* dst, int D, hipStream_t st) {
 }  // namespace hmm
 
 using namespace hmm;
-
-extern "C" int hmm_op_rowstat_bf16(const uint16_t* xb_dev, float* rs_dev, int rows, int dim, float eps, hmm_stream_t stream) {
-    HMM_REQUIRE(xb_dev && rs_dev && rows >= 1, HMM_E_INVALID, "rowstat: bad arguments");
-    return hmm::launch_rowstat_bf16(reinterpret_cast<const hmm::bf16_t*>(xb_dev), reinterpret_cast<float2*>(rs_dev), rows, dim, eps,
-                                    static_cast<hipStream_t>(stream));
-}
-
-extern "C" int hmm_op_rowstat_finalize(const float* part_dev, float* rs_dev, int rows, int dim, float eps, hmm_stream_t stream) {
-    HMM_REQUIRE(part_dev && rs_dev && rows >= 1, HMM_E_INVALID, "rowstat_finalize: bad arguments");
-    return hmm::launch_rowstat_finalize(reinterpret_cast<const float2*>(part_dev), reinterpret_cast<float2*>(rs_dev), rows, dim, eps,
-                                        static_cast<hipStream_t>(stream));
-}
-
-extern "C" int hmm_op_fold_ln_weights(const float* w0_dev, const float* gamma_dev, const float* beta_dev, const float* bias_dev,
-                                      uint16_t* wf_dev, float* c1_dev, float* c2_dev, int n, int dim, hmm_stream_t stream) {
-    HMM_REQUIRE(w0_dev && gamma_dev && beta_dev && bias_dev && wf_dev && c1_dev && c2_dev && n >= 1 && dim >= 1, HMM_E_INVALID,
-                "fold_ln_weights: bad arguments");
-    return hmm::launch_fold_ln_weights(w0_dev, gamma_dev, beta_dev, bias_dev, reinterpret_cast<hmm::bf16_t*>(wf_dev), c1_dev, c2_dev,
-                                       n, dim, static_cast<hipStream_t>(stream));
-}
 
 extern "C" int hmm_op_layernorm_bf16(const float* x_dev, const float* gamma_dev, const float* beta_dev,
                                      uint16_t* y_dev, int rows, int D, float eps, hmm_stream_t stream) {

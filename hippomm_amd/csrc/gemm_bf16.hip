@@ -45,38 +45,15 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // software-pipelined one row-block ahead so that its load latency is not paid per element.
 template <int EPI, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float* __restrict__ bias,
-                                              void* __restrict__ Cout, int M, int N, int m_lane, int n_lane,
-                                              const GemmAux& aux) {
+                                              void* __restrict__ Cout, int M, int N, int m_lane, int n_lane) {
     float4 bv[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
         bv[ni] = bias ? *reinterpret_cast<const float4*>(bias + n_lane + ni * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    if constexpr (EPI == HMM_EPI_LN_BF16 || EPI == HMM_EPI_LN_GELU_BF16) {
-        float4 c1v[NI];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) c1v[ni] = *reinterpret_cast<const float4*>(aux.c1 + n_lane + ni * 16);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int m = m_lane + mi * 16;
-            if (m >= M) continue;
-            const float2 rs = aux.rs[(size_t)m * aux.rs_stride];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                f32x4 v = acc[mi][ni];
-                v[0] = ln_fold(v[0], rs, c1v[ni].x, bv[ni].x); v[1] = ln_fold(v[1], rs, c1v[ni].y, bv[ni].y);
-                v[2] = ln_fold(v[2], rs, c1v[ni].z, bv[ni].z); v[3] = ln_fold(v[3], rs, c1v[ni].w, bv[ni].w);
-                if constexpr (EPI == HMM_EPI_LN_GELU_BF16) {
-                    v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-                }
-                bf16x4 o4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(Cout) + (size_t)m * N + n_lane + ni * 16) = o4;
-            }
-        }
-    } else if constexpr (EPI == HMM_EPI_BIAS_RESID_F32 || EPI == HMM_EPI_BIAS_RESID_XB) {
+    if constexpr (EPI == HMM_EPI_BIAS_RESID_F32) {
         float* C = static_cast<float*>(Cout);
         float4 xin[2][NI];
-        float4 xbv[NI];
         auto load_row = [&](int mi, float4 (&dst)[NI]) {
             const int m = m_lane + mi * 16;
             if (m < M) {
@@ -100,34 +77,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float*
                     const float4 o = make_float4((v[0] + bv[ni].x) + x.x, (v[1] + bv[ni].y) + x.y, (v[2] + bv[ni].z) + x.z,
                                                  (v[3] + bv[ni].w) + x.w);
                     *reinterpret_cast<float4*>(C + (size_t)m * N + n_lane + ni * 16) = o;
-                    if constexpr (EPI == HMM_EPI_BIAS_RESID_XB) {
-                        bf16x4 o4 = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
-                        *reinterpret_cast<bf16x4*>(aux.xb + (size_t)m * N + n_lane + ni * 16) = o4;
-                        xbv[ni] = make_float4((float)o4[0], (float)o4[1], (float)o4[2], (float)o4[3]);
-                    }
-                }
-                if constexpr (EPI == HMM_EPI_BIAS_RESID_XB) {
-                    // chunk statistics of the 64 columns of this wave tile (encoder_ops.h): leaf j = 4 ni + (lane >> 4); the lanes
-                    // 16 / 32 apart hold the same row (same m), so they are in this branch together
-                    static_assert(NI == 4, "chunk statistics: the wave tile must be 64 columns wide");
-                    float l[NI];
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        l[ni] = chunk_leaf_sum(xbv[ni].x, xbv[ni].y, xbv[ni].z, xbv[ni].w);
-                        l[ni] += __shfl_xor(l[ni], 16, 64);
-                        l[ni] += __shfl_xor(l[ni], 32, 64);
-                    }
-                    const float s = (l[0] + l[1]) + (l[2] + l[3]);
-                    const float mc = s * (1.0f / 64.0f);
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        l[ni] = chunk_leaf_sq(xbv[ni].x, xbv[ni].y, xbv[ni].z, xbv[ni].w, mc);
-                        l[ni] += __shfl_xor(l[ni], 16, 64);
-                        l[ni] += __shfl_xor(l[ni], 32, 64);
-                    }
-                    const float q = (l[0] + l[1]) + (l[2] + l[3]);
-                    if (aux.part != nullptr && (n_lane & 63) == 0)
-                        aux.part[(size_t)m * (N >> 6) + (n_lane >> 6)] = make_float2(s, q);
                 }
             }
         }
@@ -162,7 +111,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float*
 template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    void* __restrict__ Cout, int M, int N, int K, int tiles_n, GemmAux aux) {
+    void* __restrict__ Cout, int M, int N, int K, int tiles_n) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
@@ -308,7 +257,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
     }
 
     // epilogue: lane holds C[m][n .. n+3]
-    gemm_epilogue<EPI, MI, NI>(acc, bias, Cout, M, N, m0 + wm * TM + (lane & 15), n0 + wn * TN + 4 * (lane >> 4), aux);
+    gemm_epilogue<EPI, MI, NI>(acc, bias, Cout, M, N, m0 + wm * TM + (lane & 15), n0 + wn * TN + 4 * (lane >> 4));
 }
 
 
@@ -325,7 +274,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
 template <int EPI, int MT, int DEPTH>
 __global__ __launch_bounds__(64) void gemm_bf16_sliver_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    void* __restrict__ Cout, int M, int N, int K, int tiles_m, GemmAux aux) {
+    void* __restrict__ Cout, int M, int N, int K, int tiles_m) {
     const int lane = threadIdx.x;
     const int frow = lane & 15, g = lane >> 4;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -387,7 +336,7 @@ __global__ __launch_bounds__(64) void gemm_bf16_sliver_kernel(
             }
         }
     }
-    gemm_epilogue<EPI, MT, 1>(acc, bias, Cout, M, N, m0 + frow, n0 + 4 * g, aux);
+    gemm_epilogue<EPI, MT, 1>(acc, bias, Cout, M, N, m0 + frow, n0 + 4 * g);
 }
 
 // LDS-transposed epilogue of the ping-pong kernel.  The MFMA leaves a lane with 4 consecutive
@@ -403,42 +352,21 @@ constexpr int kEpiSlab = 18432;                      // per-wave LDS slab: 128 r
 // predicates, so the compiler batches the slab reads and keeps the loads / stores back to back.  Addresses are a
 // wave-uniform base (C + m_wave * N + n_wave, scalar registers) plus a 32-bit per-lane byte offset; each row step adds a
 // uniform amount.  (With per-row guards and 64-bit per-lane addresses the fp32 epilogue was 1,400 instructions per wave and
-// waited for every slab read on its own; RESID_XB 3,500.)
+// waited for every slab read on its own.)
 template <int EPI, bool GUARD>
 __device__ __forceinline__ void gemm_epilogue_lds_body(f32x4 (&acc)[8][4], const float4 (&bv)[4], void* __restrict__ Cout,
-                                                       int M, int N, int m_wave, int n_wave, char* slab, int lane,
-                                                       const GemmAux& aux) {
+                                                       int M, int N, int m_wave, int n_wave, char* slab, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
     const int rows_left = M - m_wave;                            // GUARD: rows [0, rows_left) of the wave tile exist
-    constexpr bool LNF = EPI == HMM_EPI_LN_BF16 || EPI == HMM_EPI_LN_GELU_BF16;
-    if constexpr (EPI == HMM_EPI_BIAS_BF16 || EPI == HMM_EPI_BIAS_GELU_BF16 || LNF) {
+    if constexpr (EPI == HMM_EPI_BIAS_BF16 || EPI == HMM_EPI_BIAS_GELU_BF16) {
         constexpr int RS = 144;
-        float4 c1v[4];
-        if constexpr (LNF) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) c1v[ni] = *reinterpret_cast<const float4*>(aux.c1 + n_wave + ni * 16 + 4 * fq);
-        }
-        float2 rsv[8];
-        if constexpr (LNF) {                                     // all eight row statistics first: one latency, not eight
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                int r = mi * 16 + fr;
-                if (GUARD) r = r < rows_left ? r : rows_left - 1;
-                rsv[mi] = aux.rs[(size_t)(m_wave + r) * aux.rs_stride];
-            }
-        }
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 f32x4 v = acc[mi][ni];
-                if constexpr (LNF) {
-                    v[0] = ln_fold(v[0], rsv[mi], c1v[ni].x, bv[ni].x); v[1] = ln_fold(v[1], rsv[mi], c1v[ni].y, bv[ni].y);
-                    v[2] = ln_fold(v[2], rsv[mi], c1v[ni].z, bv[ni].z); v[3] = ln_fold(v[3], rsv[mi], c1v[ni].w, bv[ni].w);
-                } else {
-                    v[0] += bv[ni].x; v[1] += bv[ni].y; v[2] += bv[ni].z; v[3] += bv[ni].w;
-                }
-                if constexpr (EPI == HMM_EPI_BIAS_GELU_BF16 || EPI == HMM_EPI_LN_GELU_BF16) {
+                v[0] += bv[ni].x; v[1] += bv[ni].y; v[2] += bv[ni].z; v[3] += bv[ni].w;
+                if constexpr (EPI == HMM_EPI_BIAS_GELU_BF16) {
                     v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
                 }
                 bf16x4 o4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
@@ -460,7 +388,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_body(f32x4 (&acc)[8][4], const
         }
     } else {
         constexpr int RS = 272;
-        constexpr bool RESID = EPI == HMM_EPI_BIAS_RESID_F32 || EPI == HMM_EPI_BIAS_RESID_XB;
+        constexpr bool RESID = EPI == HMM_EPI_BIAS_RESID_F32;
         char* Cw = reinterpret_cast<char*>(static_cast<float*>(Cout) + (size_t)m_wave * N + n_wave);      // wave-uniform
         const int rsub = lane >> 4, chunk = lane & 15;
         const unsigned lane_off = (unsigned)(rsub * N + chunk * 4) * 4u;
@@ -468,7 +396,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_body(f32x4 (&acc)[8][4], const
         // Software-pipelined over 16-row groups: the residual rows of a group are requested one 32-row quarter before they
         // are needed, into the registers the group of the previous quarter has just been added from -- a quarter never
         // waits a full HBM latency and only 32 registers of residual are live beside the accumulators (with both 64-row
-        // halves in flight, 128 registers, the RESID_XB variant spilled 70 registers to scratch).
+        // halves in flight, 128 registers, a variant with more epilogue work spilled 70 registers to scratch).
         float4 xin[8];
         auto load_resid = [&](int q, int g) {                    // rows 32 q + 16 g .. + 15 of the wave tile
 #pragma unroll
@@ -519,63 +447,6 @@ __device__ __forceinline__ void gemm_epilogue_lds_body(f32x4 (&acc)[8][4], const
                             *reinterpret_cast<float4*>(Cw + (q * 8 + it) * row_step + lane_off) = v[i];
                     }
                 }
-                if constexpr (EPI == HMM_EPI_BIAS_RESID_XB) {
-                    // The bf16 image of the new residual rows and its chunk statistics (encoder_ops.h).  Statistics: leaf j =
-                    // chunk, butterfly over the DPP row; the four rows are reduced side by side (independent chains).
-                    uint2 xb[4];
-                    float s[4], sq[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        bf16x4 o4 = {(bf16_t)v[i].x, (bf16_t)v[i].y, (bf16_t)v[i].z, (bf16_t)v[i].w};
-                        xb[i] = __builtin_bit_cast(uint2, o4);
-                        v[i] = make_float4((float)o4[0], (float)o4[1], (float)o4[2], (float)o4[3]);
-                        s[i] = chunk_leaf_sum(v[i].x, v[i].y, v[i].z, v[i].w);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) s[i] += dpp_mov_f32<0xB1>(s[i]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) s[i] += dpp_mov_f32<0x4E>(s[i]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) s[i] += dpp_mov_f32<0x141>(s[i]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) s[i] += dpp_mov_f32<0x140>(s[i]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sq[i] = chunk_leaf_sq(v[i].x, v[i].y, v[i].z, v[i].w, s[i] * (1.0f / 64.0f));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sq[i] += dpp_mov_f32<0xB1>(sq[i]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sq[i] += dpp_mov_f32<0x4E>(sq[i]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sq[i] += dpp_mov_f32<0x141>(sq[i]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sq[i] += dpp_mov_f32<0x140>(sq[i]);
-                    if (aux.part != nullptr && chunk == 0) {
-                        float2* pw = aux.part + (size_t)m_wave * (N >> 6) + (n_wave >> 6);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int row = q * 32 + (g * 4 + i) * 4 + rsub;
-                            if (!GUARD || row < rows_left) pw[(size_t)row * (N >> 6)] = make_float2(s[i], sq[i]);
-                        }
-                    }
-                    // xb, 16 B per lane: a lane holds 4 columns (8 B) of rows i and i + 1; neighbours (chunk ^ 1) swap halves so
-                    // that the even lane stores 8 columns of the first row and the odd lane 8 columns of the second -- whole
-                    // 128-B lines, half the store instructions.
-                    char* Xw = reinterpret_cast<char*>(aux.xb + (size_t)m_wave * N + n_wave);
-                    const bool odd = chunk & 1;
-                    const unsigned xoff = (unsigned)(rsub * N + (chunk & ~1) * 4) * 2u;
-#pragma unroll
-                    for (int i = 0; i < 4; i += 2) {
-                        const uint2 send = odd ? xb[i] : xb[i + 1];          // what the neighbour stores: its row's other half
-                        uint2 recv;
-                        recv.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xF, 0xF, true);
-                        recv.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xF, 0xF, true);
-                        const int rbase = q * 32 + (g * 4 + i + (odd ? 1 : 0)) * 4;    // odd lanes store row i + 1, even lanes row i
-                        const uint4 qd = odd ? make_uint4(recv.x, recv.y, xb[i + 1].x, xb[i + 1].y)
-                                             : make_uint4(xb[i].x, xb[i].y, recv.x, recv.y);
-                        if (!GUARD || rbase + rsub < rows_left)
-                            *reinterpret_cast<uint4*>(Xw + (unsigned)rbase * (unsigned)N * 2u + xoff) = qd;
-                    }
-                }
             }
         };
         auto slab_free = [&]() {                                 // the slab is re-used: its reads must be done
@@ -596,16 +467,16 @@ __device__ __forceinline__ void gemm_epilogue_lds_body(f32x4 (&acc)[8][4], const
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const float* __restrict__ bias,
                                                   void* __restrict__ Cout, int M, int N, int m_wave, int n_wave,
-                                                  char* slab, int lane, const GemmAux& aux) {
+                                                  char* slab, int lane) {
     const int fq = lane >> 4;
     float4 bv[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
         bv[ni] = bias ? *reinterpret_cast<const float4*>(bias + n_wave + ni * 16 + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (m_wave + 128 <= M)                                       // wave-uniform
-        gemm_epilogue_lds_body<EPI, false>(acc, bv, Cout, M, N, m_wave, n_wave, slab, lane, aux);
+        gemm_epilogue_lds_body<EPI, false>(acc, bv, Cout, M, N, m_wave, n_wave, slab, lane);
     else if (m_wave < M)
-        gemm_epilogue_lds_body<EPI, true>(acc, bv, Cout, M, N, m_wave, n_wave, slab, lane, aux);
+        gemm_epilogue_lds_body<EPI, true>(acc, bv, Cout, M, N, m_wave, n_wave, slab, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -645,7 +516,7 @@ HMM_TUNABLE(int, g_gemm_skip_tail, 0)   // probe build: 1 = do not launch the pe
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    void* __restrict__ Cout, int M, int N, int K, int tiles_n, int walk, GemmAux aux HMM_PROBE_ARG) {
+    void* __restrict__ Cout, int M, int N, int K, int tiles_n, int walk HMM_PROBE_ARG) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -705,7 +576,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 #ifdef HMM_PROBE
     if (stamps && threadIdx.x == 0) stamps[(size_t)bid * 8 + 7] = __builtin_amdgcn_s_memtime();     // shader-clock ticks
 #endif
-    gemm_epilogue_lds<EPI>(acc, bias, Cout, M, N, m0 + wm * 128, n0 + wn * 64, smem + wave * kEpiSlab, lane, aux);
+    gemm_epilogue_lds<EPI>(acc, bias, Cout, M, N, m0 + wm * 128, n0 + wn * 64, smem + wave * kEpiSlab, lane);
 #ifdef HMM_PROBE
     if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     HMM_STAMP(3)
@@ -714,26 +585,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 
 template <int EPI>
 static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                          const GemmAux& aux, hipStream_t st) {
+                          hipStream_t st) {
     constexpr int LDS = 8 * kEpiSlab > 2 * 4 * 16384 ? 8 * kEpiSlab : 2 * 4 * 16384;
     const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
     auto kern = gemm_bf16_pp_kernel<EPI>;
     HMM_ENSURE_DYN_LDS(kern, LDS);
     int grid = tiles_m * tiles_n;
     if (g_gemm_trunc_rounds && grid > 256 && grid % 256 > 64) grid = grid / 256 * 256;   // probe build, timing only: whole rounds
-    kern<<<grid, 512, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n, pick_walk(tiles_m, tiles_n), aux HMM_PROBE_VAL);
+    kern<<<grid, 512, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n, pick_walk(tiles_m, tiles_n) HMM_PROBE_VAL);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2>
 static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                       const GemmAux& aux, hipStream_t st) {
+                       hipStream_t st) {
     constexpr int LDS = STAGES * (BM + BN) * 128;
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, STAGES>;
     HMM_ENSURE_DYN_LDS(kern, LDS);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
-    kern<<<tiles_m * tiles_n, WM * WN * 64, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n, aux);
+    kern<<<tiles_m * tiles_n, WM * WN * 64, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
@@ -770,23 +641,23 @@ static bool sliver_wins(int M, int N, int K, int epi) {
 
 template <int EPI>
 static int launch_gemm_sliver(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                              const GemmAux& aux, hipStream_t st) {
+                              hipStream_t st) {
     const int mt = sliver_mt(M, N, K);
     const int tiles_m = (M + 16 * mt - 1) / (16 * mt), grid = tiles_m * (N / 16);
-    if (mt == 1) gemm_bf16_sliver_kernel<EPI, 1, 8><<<grid, 64, 0, st>>>(A, W, bias, C, M, N, K, tiles_m, aux);
-    else if (mt == 2) gemm_bf16_sliver_kernel<EPI, 2, 6><<<grid, 64, 0, st>>>(A, W, bias, C, M, N, K, tiles_m, aux);
-    else gemm_bf16_sliver_kernel<EPI, 4, 4><<<grid, 64, 0, st>>>(A, W, bias, C, M, N, K, tiles_m, aux);
+    if (mt == 1) gemm_bf16_sliver_kernel<EPI, 1, 8><<<grid, 64, 0, st>>>(A, W, bias, C, M, N, K, tiles_m);
+    else if (mt == 2) gemm_bf16_sliver_kernel<EPI, 2, 6><<<grid, 64, 0, st>>>(A, W, bias, C, M, N, K, tiles_m);
+    else gemm_bf16_sliver_kernel<EPI, 4, 4><<<grid, 64, 0, st>>>(A, W, bias, C, M, N, K, tiles_m);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
 
 static int launch_gemm_sliver_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                                  int epi, const GemmAux& aux, hipStream_t st) {
+                                  int epi, hipStream_t st) {
     switch (epi) {
-        case HMM_EPI_BIAS_BF16:      return launch_gemm_sliver<HMM_EPI_BIAS_BF16>(A, W, bias, C, M, N, K, aux, st);
-        case HMM_EPI_BIAS_GELU_BF16: return launch_gemm_sliver<HMM_EPI_BIAS_GELU_BF16>(A, W, bias, C, M, N, K, aux, st);
-        case HMM_EPI_BIAS_RESID_F32: return launch_gemm_sliver<HMM_EPI_BIAS_RESID_F32>(A, W, bias, C, M, N, K, aux, st);
-        case HMM_EPI_F32:            return launch_gemm_sliver<HMM_EPI_F32>(A, W, bias, C, M, N, K, aux, st);
+        case HMM_EPI_BIAS_BF16:      return launch_gemm_sliver<HMM_EPI_BIAS_BF16>(A, W, bias, C, M, N, K, st);
+        case HMM_EPI_BIAS_GELU_BF16: return launch_gemm_sliver<HMM_EPI_BIAS_GELU_BF16>(A, W, bias, C, M, N, K, st);
+        case HMM_EPI_BIAS_RESID_F32: return launch_gemm_sliver<HMM_EPI_BIAS_RESID_F32>(A, W, bias, C, M, N, K, st);
+        case HMM_EPI_F32:            return launch_gemm_sliver<HMM_EPI_F32>(A, W, bias, C, M, N, K, st);
     }
     set_error("gemm: the sliver kernel has no epilogue %d", epi);
     return HMM_E_INVALID;
@@ -798,17 +669,14 @@ static int launch_gemm_sliver_epi(const bf16_t* A, const bf16_t* W, const float*
         case HMM_EPI_BIAS_GELU_BF16: return CALL(HMM_EPI_BIAS_GELU_BF16);                 \
         case HMM_EPI_BIAS_RESID_F32: return CALL(HMM_EPI_BIAS_RESID_F32);                 \
         case HMM_EPI_F32:            return CALL(HMM_EPI_F32);                            \
-        case HMM_EPI_BIAS_RESID_XB:  return CALL(HMM_EPI_BIAS_RESID_XB);                  \
-        case HMM_EPI_LN_BF16:        return CALL(HMM_EPI_LN_BF16);                        \
-        case HMM_EPI_LN_GELU_BF16:   return CALL(HMM_EPI_LN_GELU_BF16);                   \
     }                                                                                     \
     set_error("gemm: unknown epilogue %d", epi);                                          \
     return HMM_E_INVALID;
 
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                           int epi, const GemmAux& aux, hipStream_t st) {
-#define HMM_CALL(E) launch_gemm<BM, BN, WM, WN, E>(A, W, bias, C, M, N, K, aux, st)
+                           int epi, hipStream_t st) {
+#define HMM_CALL(E) launch_gemm<BM, BN, WM, WN, E>(A, W, bias, C, M, N, K, st)
     HMM_EPI_SWITCH(HMM_CALL)
 #undef HMM_CALL
 }
@@ -818,15 +686,13 @@ static int launch_gemm_epi(const bf16_t* A, const bf16_t* W, const float* bias, 
 // fragments of the next K-tile read under the MFMAs of the current one 0.25 -- the step is the barrier, the DMA issue and the
 // dependent read -> MFMA chain, not bytes in flight; eight waves of 32x16 per tile (two per SIMD) 0.25.
 static int launch_gemm_ring64_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                                  int epi, const GemmAux& aux, hipStream_t st) {
-#define HMM_CALL(E) launch_gemm<64, 64, 2, 2, E, 4>(A, W, bias, C, M, N, K, aux, st)
-    switch (epi) {                                   // not RESID_XB: its chunk statistics need a 64-column wave tile
+                                  int epi, hipStream_t st) {
+#define HMM_CALL(E) launch_gemm<64, 64, 2, 2, E, 4>(A, W, bias, C, M, N, K, st)
+    switch (epi) {
         case HMM_EPI_BIAS_BF16:      return HMM_CALL(HMM_EPI_BIAS_BF16);
         case HMM_EPI_BIAS_GELU_BF16: return HMM_CALL(HMM_EPI_BIAS_GELU_BF16);
         case HMM_EPI_BIAS_RESID_F32: return HMM_CALL(HMM_EPI_BIAS_RESID_F32);
         case HMM_EPI_F32:            return HMM_CALL(HMM_EPI_F32);
-        case HMM_EPI_LN_BF16:        return HMM_CALL(HMM_EPI_LN_BF16);
-        case HMM_EPI_LN_GELU_BF16:   return HMM_CALL(HMM_EPI_LN_GELU_BF16);
     }
 #undef HMM_CALL
     set_error("gemm: 64x64 tiles have no epilogue %d", epi);
@@ -834,8 +700,8 @@ static int launch_gemm_ring64_epi(const bf16_t* A, const bf16_t* W, const float*
 }
 
 static int launch_gemm_ring32_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                                  int epi, const GemmAux& aux, hipStream_t st) {
-#define HMM_CALL(E) launch_gemm<32, 32, 2, 2, E, 4>(A, W, bias, C, M, N, K, aux, st)
+                                  int epi, hipStream_t st) {
+#define HMM_CALL(E) launch_gemm<32, 32, 2, 2, E, 4>(A, W, bias, C, M, N, K, st)
     switch (epi) {
         case HMM_EPI_BIAS_BF16:      return HMM_CALL(HMM_EPI_BIAS_BF16);
         case HMM_EPI_BIAS_GELU_BF16: return HMM_CALL(HMM_EPI_BIAS_GELU_BF16);
@@ -848,8 +714,8 @@ static int launch_gemm_ring32_epi(const bf16_t* A, const bf16_t* W, const float*
 }
 
 static int launch_gemm_ring128_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                                   int epi, const GemmAux& aux, hipStream_t st) {
-#define HMM_CALL(E) launch_gemm<128, 128, 2, 2, E, 4>(A, W, bias, C, M, N, K, aux, st)
+                                   int epi, hipStream_t st) {
+#define HMM_CALL(E) launch_gemm<128, 128, 2, 2, E, 4>(A, W, bias, C, M, N, K, st)
     HMM_EPI_SWITCH(HMM_CALL)
 #undef HMM_CALL
 }
@@ -868,36 +734,32 @@ int gemm_set_small_tiles(int tiles) {
 }
 HMM_TUNABLE(int, g_gemm_tail_64, 128)      // the peeled last row tile of a big launch uses 64x64 tiles up to this many of them
 static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                                 int epi, const GemmAux& aux, hipStream_t st, bool tail = false) {
+                                 int epi, hipStream_t st, bool tail = false) {
     if (g_gemm_small_stages == 2 || (long)((M + 127) / 128) * (N / 128) > 256)
-        return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
-    if (!tail && epi <= HMM_EPI_F32 && ring32_fits(M, N)) return launch_gemm_ring32_epi(A, W, bias, C, M, N, K, epi, aux, st);
-    if (g_gemm_small_64 && epi != HMM_EPI_BIAS_RESID_XB &&
+        return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
+    if (!tail && epi <= HMM_EPI_F32 && ring32_fits(M, N)) return launch_gemm_ring32_epi(A, W, bias, C, M, N, K, epi, st);
+    if (g_gemm_small_64 &&
         (long)((M + 63) / 64) * (N / 64) <= (tail ? g_gemm_tail_64 : g_gemm_small_64))
-        return launch_gemm_ring64_epi(A, W, bias, C, M, N, K, epi, aux, st);
-    return launch_gemm_ring128_epi(A, W, bias, C, M, N, K, epi, aux, st);
+        return launch_gemm_ring64_epi(A, W, bias, C, M, N, K, epi, st);
+    return launch_gemm_ring128_epi(A, W, bias, C, M, N, K, epi, st);
 }
 
 static int launch_gemm_pp_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
-                              int epi, const GemmAux& aux, hipStream_t st) {
+                              int epi, hipStream_t st) {
     if ((size_t)M * K >= (1ull << 31) || (size_t)N * K >= (1ull << 31))       // 32-bit staging offsets
-        return launch_gemm_epi<256, 256, 2, 4>(A, W, bias, C, M, N, K, epi, aux, st);
-#define HMM_CALL(E) launch_gemm_pp<E>(A, W, bias, C, M, N, K, aux, st)
+        return launch_gemm_epi<256, 256, 2, 4>(A, W, bias, C, M, N, K, epi, st);
+#define HMM_CALL(E) launch_gemm_pp<E>(A, W, bias, C, M, N, K, st)
     HMM_EPI_SWITCH(HMM_CALL)
 #undef HMM_CALL
 }
 #undef HMM_EPI_SWITCH
 
 int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int epi,
-              int tile, hipStream_t st, const GemmAux* aux_in) {
-    const GemmAux aux = aux_in ? *aux_in : GemmAux{};
+              int tile, hipStream_t st) {
     HMM_REQUIRE(A && W && C, HMM_E_INVALID, "gemm: null pointer");
     HMM_REQUIRE(M >= 1 && N >= 128 && K >= 64 && K % 64 == 0 && N % 128 == 0, HMM_E_INVALID,
                 "gemm: unsupported shape M=%d N=%d K=%d (need K%%64==0, N%%128==0)", M, N, K);
     HMM_REQUIRE(epi == HMM_EPI_F32 || bias != nullptr, HMM_E_INVALID, "gemm: epilogue %d needs a bias", epi);
-    HMM_REQUIRE(epi != HMM_EPI_BIAS_RESID_XB || aux.xb != nullptr, HMM_E_INVALID, "gemm: epilogue %d needs aux.xb", epi);
-    HMM_REQUIRE((epi != HMM_EPI_LN_BF16 && epi != HMM_EPI_LN_GELU_BF16) || (aux.rs != nullptr && aux.c1 != nullptr && aux.rs_stride >= 1),
-                HMM_E_INVALID, "gemm: epilogue %d needs aux.rs and aux.c1", epi);
     const bool sliver_ok = tile == HMM_GEMM_TILE_AUTO;          // AUTO_TILED, and every named geometry: tiled kernels only
     if (tile < 0) tile = HMM_GEMM_TILE_PP_PEELED;
     const bool pp_ok = N % 256 == 0 && K % 128 == 0;
@@ -912,8 +774,8 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         const long tiles = (long)tiles_m * tiles_n;
         // few 256x256 tiles (cls-only last block, head): 128x128 tiles put 4x more CUs to work
         if (tiles < t_gemm_small_tiles)
-            return sliver_ok && sliver_wins(M, N, K, epi) ? launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, aux, st)
-                                             : launch_gemm_small_epi(A, W, bias, C, M, N, K, epi, aux, st);
+            return sliver_ok && sliver_wins(M, N, K, epi) ? launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, st)
+                                             : launch_gemm_small_epi(A, W, bias, C, M, N, K, epi, st);
         // peel p <= 2 row tiles when that leaves the main launch with a last round that is full or nearly full (>= 240 of 256
         // CUs) instead of a nearly empty one
         int peel = 0;
@@ -922,30 +784,24 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
                 const long r = ((long)(tiles_m - p) * tiles_n) % 256;
                 if (r == 0 || r >= 240) peel = p;
             }
-        if (!peel) return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, aux, st);
+        if (!peel) return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, st);
         const int m_main = (tiles_m - peel) * 256;
-        int rc = launch_gemm_pp_epi(A, W, bias, C, m_main, N, K, epi, aux, st);
+        int rc = launch_gemm_pp_epi(A, W, bias, C, m_main, N, K, epi, st);
         if (rc != HMM_OK) return rc;
         if (g_gemm_skip_tail) return rc;                         // probe build only (timing upper bound; results are wrong)
-        const bool c_bf16 = epi == HMM_EPI_BIAS_BF16 || epi == HMM_EPI_BIAS_GELU_BF16 || epi == HMM_EPI_LN_BF16 ||
-                            epi == HMM_EPI_LN_GELU_BF16;
-        GemmAux tail = aux;                                      // the per-row operands move with the rows
-        if (tail.xb) tail.xb += (size_t)m_main * N;
-        if (tail.part) tail.part += (size_t)m_main * (N >> 6);
-        if (tail.rs) tail.rs += (size_t)m_main * aux.rs_stride;
+        const bool c_bf16 = epi == HMM_EPI_BIAS_BF16 || epi == HMM_EPI_BIAS_GELU_BF16;
         return launch_gemm_small_epi(A + (size_t)m_main * K, W, bias,
-                                     static_cast<char*>(C) + (size_t)m_main * N * (c_bf16 ? 2 : 4), M - m_main, N, K, epi, tail, st,
-                                     true);
+                                     static_cast<char*>(C) + (size_t)m_main * N * (c_bf16 ? 2 : 4), M - m_main, N, K, epi, st, true);
     }
     switch (tile) {
-        case HMM_GEMM_TILE_SLIVER:     return launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, aux, st);
-        case HMM_GEMM_TILE_128x128_RING: return launch_gemm_ring128_epi(A, W, bias, C, M, N, K, epi, aux, st);
-        case HMM_GEMM_TILE_64x64_RING:   return launch_gemm_ring64_epi(A, W, bias, C, M, N, K, epi, aux, st);
-        case HMM_GEMM_TILE_32x32_RING:   return launch_gemm_ring32_epi(A, W, bias, C, M, N, K, epi, aux, st);
-        case HMM_GEMM_TILE_256x256_PP: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, aux, st);
-        case HMM_GEMM_TILE_128x128:    return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
-        case HMM_GEMM_TILE_256x128:    return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, aux, st);
-        case HMM_GEMM_TILE_256x256:    return launch_gemm_epi<256, 256, 2, 4>(A, W, bias, C, M, N, K, epi, aux, st);
+        case HMM_GEMM_TILE_SLIVER:     return launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_128x128_RING: return launch_gemm_ring128_epi(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_64x64_RING:   return launch_gemm_ring64_epi(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_32x32_RING:   return launch_gemm_ring32_epi(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_256x256_PP: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_128x128:    return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_256x128:    return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_256x256:    return launch_gemm_epi<256, 256, 2, 4>(A, W, bias, C, M, N, K, epi, st);
     }
     set_error("gemm: unknown tile geometry %d", tile);
     return HMM_E_INVALID;
@@ -965,22 +821,4 @@ extern "C" int hmm_op_gemm_bf16_tile(const uint16_t* a_dev, const uint16_t* w_de
                                      void* c_dev, int M, int N, int K, int epilogue, int tile, hmm_stream_t stream) {
     return gemm_bf16(reinterpret_cast<const bf16_t*>(a_dev), reinterpret_cast<const bf16_t*>(w_dev), bias_dev, c_dev,
                      M, N, K, epilogue, tile, static_cast<hipStream_t>(stream));
-}
-
-extern "C" int hmm_op_gemm_bf16_ln(const uint16_t* a_dev, const uint16_t* wf_dev, const float* c2_dev, uint16_t* c_dev, int M,
-                                   int N, int K, int gelu, const float* rs_dev, int rs_stride, const float* c1_dev, int tile,
-                                   hmm_stream_t stream) {
-    GemmAux aux;
-    aux.rs = reinterpret_cast<const float2*>(rs_dev); aux.rs_stride = rs_stride; aux.c1 = c1_dev;
-    return gemm_bf16(reinterpret_cast<const bf16_t*>(a_dev), reinterpret_cast<const bf16_t*>(wf_dev), c2_dev, c_dev, M, N, K,
-                     gelu ? HMM_EPI_LN_GELU_BF16 : HMM_EPI_LN_BF16, tile, static_cast<hipStream_t>(stream), &aux);
-}
-
-extern "C" int hmm_op_gemm_bf16_resid_xb(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev, float* c_dev,
-                                         uint16_t* xb_dev, float* part_dev, int M, int N, int K, int tile, hmm_stream_t stream) {
-    GemmAux aux;
-    aux.xb = reinterpret_cast<bf16_t*>(xb_dev);
-    aux.part = reinterpret_cast<float2*>(part_dev);
-    return gemm_bf16(reinterpret_cast<const bf16_t*>(a_dev), reinterpret_cast<const bf16_t*>(w_dev), bias_dev, c_dev, M, N, K,
-                     HMM_EPI_BIAS_RESID_XB, tile, static_cast<hipStream_t>(stream), &aux);
 }

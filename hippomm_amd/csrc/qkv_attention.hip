@@ -49,15 +49,11 @@ struct FusedPlan {
     static_assert(G::T + (G::BIAS_KV ? 1 : 0) <= Cfg::NKEY && G::T - G::ROW0 <= 256 && 3 * G::DH <= 256, "tile geometry");
 };
 
-// LNF (folded LayerNorm, encoder.hip): `a` is the bf16 image of the residual stream, `w` = bf16(gamma (.) in_proj_weight),
-// `bias` = c2 and the projection value is fma(rs.x, acc, fma(-rs.y, c1, c2)) with rs[row] = (rstd, rstd * mean) -- the same
-// expression as gemm_bf16's HMM_EPI_LN_BF16 epilogue, so the two routes stay bitwise equal.
-template <class G, bool LNF>
+template <class G>
 __global__ __launch_bounds__(512) void qkv_attention_kernel(
     const bf16_t* __restrict__ a /* [n_img*T][D] LayerNorm output */, const bf16_t* __restrict__ w /* [3D][D] */,
     const float* __restrict__ bias /* [3D] */, const bf16_t* __restrict__ qkv_cls /* [n_img][3D], CLS_OUTSIDE only */,
     bf16_t* __restrict__ out /* [n_img*T][D] */, int n_img, float scale_log2e,
-    const float2* __restrict__ rs /* [n_img*T] */, const float* __restrict__ c1 /* [3D] */,
     const float* __restrict__ bias_k /* [D], BIAS_KV only */, const float* __restrict__ bias_v) {
     using P = FusedPlan<G>;
     using Cfg = typename P::Cfg;
@@ -106,34 +102,19 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
     char* q_lds = smem + P::QOff;
     {
         const int fr = lane & 15, fq = lane >> 4;
-        float2 rsv[8];
-        if constexpr (LNF) {
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int tok = G::ROW0 + wm * 128 + mi * 16 + fr;
-                rsv[mi] = rs[(size_t)b * kT + (tok < kT ? tok : kT - 1)];
-            }
-        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int col = wn * 64 + ni * 16 + 4 * fq;                  // 4 consecutive tile columns, never across a part
             const int part = col / kDH, d = col - part * kDH;
             if (part < 3) {                                              // wave-uniform per (wn, ni) except vision's last group
                 const float4 bv = *reinterpret_cast<const float4*>(bias + part * kD + h * kDH + d);
-                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (LNF) cv = *reinterpret_cast<const float4*>(c1 + part * kD + h * kDH + d);
                 char* img = part == 0 ? q_lds : (part == 1 ? k_lds : v_lds);
                 const int stride = part == 0 ? P::QRow : (part == 1 ? Cfg::KROW : Cfg::VROW);
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) {
                     const int tok = G::ROW0 + wm * 128 + mi * 16 + fr;
                     const f32x4 v = acc[mi][ni];
-                    bf16x4 o4;
-                    if constexpr (LNF)
-                        o4 = bf16x4{(bf16_t)ln_fold(v[0], rsv[mi], cv.x, bv.x), (bf16_t)ln_fold(v[1], rsv[mi], cv.y, bv.y),
-                                    (bf16_t)ln_fold(v[2], rsv[mi], cv.z, bv.z), (bf16_t)ln_fold(v[3], rsv[mi], cv.w, bv.w)};
-                    else
-                        o4 = bf16x4{(bf16_t)(v[0] + bv.x), (bf16_t)(v[1] + bv.y), (bf16_t)(v[2] + bv.z), (bf16_t)(v[3] + bv.w)};
+                    const bf16x4 o4 = {(bf16_t)(v[0] + bv.x), (bf16_t)(v[1] + bv.y), (bf16_t)(v[2] + bv.z), (bf16_t)(v[3] + bv.w)};
                     if (G::ROW0 + 255 < kT || tok < kT)                  // tile rows past the last token are dropped
                         *reinterpret_cast<bf16x4*>(img + tok * stride + d * 2) = o4;
                 }
@@ -182,31 +163,29 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
                                 out + (size_t)b * kT * kD + h * kDH, kT, kT + (G::BIAS_KV ? 1 : 0), kD, scale_log2e, false);
 }
 
-template <class G, bool LNF>
+template <class G>
 static int launch_fused(const bf16_t* a, const bf16_t* w, const float* bias, const bf16_t* qkv_cls, bf16_t* out, int n_img,
-                        hipStream_t st, const float2* rs, const float* c1, const float* bias_k, const float* bias_v) {
+                        hipStream_t st, const float* bias_k, const float* bias_v) {
     HMM_REQUIRE(n_img >= 1 && (int64_t)n_img * G::T * G::D < (1ll << 31), HMM_E_INVALID, "qkv_attention: n_img=%d out of range", n_img);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)G::DH);
     const int grid = 8 * ((n_img + 7) / 8) * G::H;
-    auto kern = qkv_attention_kernel<G, LNF>;
+    auto kern = qkv_attention_kernel<G>;
     HMM_ENSURE_DYN_LDS(kern, FusedPlan<G>::Lds);
-    kern<<<grid, 512, FusedPlan<G>::Lds, st>>>(a, w, bias, qkv_cls, out, n_img, scale_log2e, rs, c1, bias_k, bias_v);
+    kern<<<grid, 512, FusedPlan<G>::Lds, st>>>(a, w, bias, qkv_cls, out, n_img, scale_log2e, bias_k, bias_v);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
 
 int qkv_attention_bf16(const bf16_t* a, const bf16_t* w, const float* bias, const bf16_t* qkv_cls, bf16_t* out,
-                       int n_img, hipStream_t st, const float2* rs, const float* c1) {
+                       int n_img, hipStream_t st) {
     HMM_REQUIRE(a && w && bias && qkv_cls && out, HMM_E_INVALID, "qkv_attention: null pointer");
-    HMM_REQUIRE((rs == nullptr) == (c1 == nullptr), HMM_E_INVALID, "qkv_attention: row statistics and c1 go together");
-    if (rs) return launch_fused<VisionGeo, true>(a, w, bias, qkv_cls, out, n_img, st, rs, c1, nullptr, nullptr);
-    return launch_fused<VisionGeo, false>(a, w, bias, qkv_cls, out, n_img, st, nullptr, nullptr, nullptr, nullptr);
+    return launch_fused<VisionGeo>(a, w, bias, qkv_cls, out, n_img, st, nullptr, nullptr);
 }
 
 int qkv_attention_audio_bf16(const bf16_t* a, const bf16_t* w, const float* bias, const float* bias_k, const float* bias_v,
                              bf16_t* out, int n_clips, hipStream_t st) {
     HMM_REQUIRE(a && w && bias && bias_k && bias_v && out, HMM_E_INVALID, "qkv_attention_audio: null pointer");
-    return launch_fused<AudioGeo, false>(a, w, bias, nullptr, out, n_clips, st, nullptr, nullptr, bias_k, bias_v);
+    return launch_fused<AudioGeo>(a, w, bias, nullptr, out, n_clips, st, bias_k, bias_v);
 }
 
 }  // namespace hmm
@@ -218,15 +197,6 @@ extern "C" int hmm_op_qkv_attention_bf16(const uint16_t* a_dev, const uint16_t* 
     return qkv_attention_bf16(reinterpret_cast<const bf16_t*>(a_dev), reinterpret_cast<const bf16_t*>(w_dev), bias_dev,
                               reinterpret_cast<const bf16_t*>(qkv_cls_dev), reinterpret_cast<bf16_t*>(out_dev), n_img,
                               static_cast<hipStream_t>(stream));
-}
-
-extern "C" int hmm_op_qkv_attention_ln_bf16(const uint16_t* xb_dev, const uint16_t* wf_dev, const float* c2_dev,
-                                            const uint16_t* qkv_cls_dev, uint16_t* out_dev, int n_img, const float* rs_dev,
-                                            const float* c1_dev, hmm_stream_t stream) {
-    HMM_REQUIRE(rs_dev && c1_dev, HMM_E_INVALID, "qkv_attention_ln: null statistics");
-    return qkv_attention_bf16(reinterpret_cast<const bf16_t*>(xb_dev), reinterpret_cast<const bf16_t*>(wf_dev), c2_dev,
-                              reinterpret_cast<const bf16_t*>(qkv_cls_dev), reinterpret_cast<bf16_t*>(out_dev), n_img,
-                              static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(rs_dev), c1_dev);
 }
 
 extern "C" int hmm_op_qkv_attention_audio_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,

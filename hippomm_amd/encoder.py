@@ -109,14 +109,15 @@ class HipTower:
         """FLOPs this build executes for the same forward (folded patch conv, cls-only last block)."""
         return float(self._lib.hmm_encoder_flops_executed(self._h, batch))
 
+    def weight_bytes(self) -> int:
+        """Bytes of the bf16 matrices one forward reads (blocks + head; embeddings, biases and norms left out): the
+        weight-stream floor of a one-sample forward."""
+        D, mlp = {"vision": (1280, 5120), "audio": (768, 3072), "text": (1024, 4096)}[self.name]
+        return 2 * (self.depth * (4 * D * D + 2 * D * mlp) + 1024 * D)
+
     def set_fused_attention(self, on: bool):
         """Vision tower: in_proj + attention as one kernel (default) or as GEMM + attention kernel; same bits."""
         _lib.check(self._lib.hmm_encoder_set_fused_attention(self._h, int(bool(on))), "hmm_encoder_set_fused_attention")
-
-    def set_folded_layernorm(self, on: bool):
-        """Vision tower: LayerNorm folded into the neighbouring GEMMs (opt-in) or run as its own kernel (default: it is
-        the faster of the two); results agree within the bf16 noise, not bitwise (include/hippomm_hip.h)."""
-        _lib.check(self._lib.hmm_encoder_set_folded_layernorm(self._h, int(bool(on))), "hmm_encoder_set_folded_layernorm")
 
     def set_streams(self, n: int):
         """2 (default): half-batches on two streams from 16 frames / 4 audio segments / 64 questions on; 1: a single chain."""

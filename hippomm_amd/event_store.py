@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import json
 import os
+import uuid
 from pathlib import Path
 from typing import Any, Dict, Iterable, List, Mapping, Optional, Tuple
 
@@ -53,19 +54,22 @@ def event_json_text(event: Any, fast: bool = True) -> str:
     ``indent`` forces Python's pure-Python encoder (~1 us per float; 0.6 s for a 600-frame event).  With ``fast`` the
     2-D feature matrices -- 99.9 % of the text -- are encoded row by row with the C encoder and re-indented by string
     replacement, which yields the same bytes (same ``float.__repr__`` digits, same separators and indentation) 2-3x
-    faster; everything else, and any matrix that is not a non-empty list of equally long float rows, goes through
-    ``json.dumps(indent=2)`` itself."""
+    faster; everything else, and any matrix that is not a non-empty list of equally long rows of Python floats (EVERY row is
+    checked), goes through ``json.dumps(indent=2)`` itself.  The hole a matrix leaves in the outer text is a fresh random
+    token; if the token turns up anywhere else in the text the whole event goes through ``json.dumps(indent=2)``."""
     d = event.to_dict() if hasattr(event, "to_dict") else event_to_dict(event)
     if not fast or not isinstance(d.get("features"), dict):
         return json.dumps(d, indent=2)
-    feats, holes = dict(d["features"]), {}
+    feats, holes, salt = dict(d["features"]), {}, uuid.uuid4().hex
     for i, (modality, rows) in enumerate(list(feats.items())):
-        if (isinstance(rows, list) and rows and all(isinstance(r, list) and r and len(r) == len(rows[0]) for r in rows)
-                and all(isinstance(v, float) for v in rows[0]) and all(isinstance(v, float) for v in rows[-1])):
-            token = f"@@hmm_matrix_{i}@@"
+        if (isinstance(rows, list) and rows and isinstance(rows[0], list) and rows[0]
+                and all(type(r) is list and len(r) == len(rows[0]) and all(type(v) is float for v in r) for r in rows)):
+            token = f"@@hmm_matrix_{i}_{salt}@@"
             holes[f'"{token}"'] = rows
             feats[modality] = token
     text = json.dumps(dict(d, features=feats), indent=2)
+    if any(text.count(quoted) != 1 for quoted in holes):         # the token also occurs in the event's own strings
+        return json.dumps(d, indent=2)
     for quoted, rows in holes.items():
         # features -> modality -> row -> value: rows sit at indent 6, values at indent 8, the closing bracket at indent 4
         body = ",\n".join("      [\n        " + json.dumps(r)[1:-1].replace(", ", ",\n        ") + "\n      ]" for r in rows)

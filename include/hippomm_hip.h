@@ -172,14 +172,6 @@ int  hmm_encoder_set_streams(hmm_encoder* enc, int n_streams);
  * bitwise identical either way.  No effect on the text tower (77 tokens would fill 30 % of the kernel's 256-row tile).
  * Forwards below 32 frames / 6 clips use the two-kernel path regardless: the fused kernel is 16 (12) workgroups per sample. */
 int  hmm_encoder_set_fused_attention(hmm_encoder* enc, int on);
-/* Vision tower, every block but the last: on (possible once all parameters are loaded; OFF by default -- measured slower than
- * the LayerNorm kernel on MI355X) = no LayerNorm pass over the residual stream.  The residual GEMMs also emit
- * xb = bf16(x) and the per-64-column chunk statistics of its rows, a small kernel combines them into (rstd, rstd * mean); in_proj
- * and fc1 run on xb with weights bf16(gamma (.) W) and finish the normalisation in their epilogue:
- *   LN(xb) W^T + b = rstd * (xb W'^T) - rstd * mean * rowsum(W') + (W beta + b).
- * off = the LayerNorm kernel (fp32 statistics of x, result rounded to bf16) + plain GEMMs, as the audio / text towers run.
- * Same function, different rounding points: results differ within the bf16 noise (parity tests hold for both). */
-int  hmm_encoder_set_folded_layernorm(hmm_encoder* enc, int on);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side vision preprocessing.  Replaces, for already decoded frames, the transform chain of
@@ -269,27 +261,6 @@ int hmm_op_qkv_attention_bf16(const uint16_t* a_dev, const uint16_t* w_dev, cons
 int hmm_op_qkv_attention_audio_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
                                     const float* bias_k_dev, const float* bias_v_dev, uint16_t* out_dev, int n_clips,
                                     hmm_stream_t stream);
-/* Folded-LayerNorm pieces (hmm_encoder_set_folded_layernorm), exported for the parity tests:
- *   hmm_op_rowstat_bf16       rs[r] = (rstd, rstd * mean) of row r of xb [rows][dim] bf16 (dim = 768 / 1024 / 1280), eps inside
- *                             the square root as nn.LayerNorm;
- *   hmm_op_fold_ln_weights    wf = bf16(gamma (.) w0) [n][dim], c1[n] = sum_k wf[n][k], c2[n] = sum_k w0[n][k] beta[k] + bias[n];
- *   hmm_op_gemm_bf16_ln       C_bf16 = [gelu](rs[m*rs_stride].x * (A wf^T) - rs[..].y * c1 + c2)   (gelu != 0: with GELU);
- *   hmm_op_gemm_bf16_resid_xb C_f32 += A W^T + bias as HMM_EPI_BIAS_RESID_F32, and xb = bf16(C_f32); part_dev (may be null):
- *                             [M][N/64] pairs (sum, sum of squares about the chunk mean) of every 64-column chunk of xb's rows;
- *   hmm_op_rowstat_finalize   rs[r] = (rstd, rstd * mean) of row r from its dim/64 chunk pairs (the statistics of
- *                             hmm_op_rowstat_bf16 without a pass over xb; agrees with it to fp32 rounding);
- *   hmm_op_qkv_attention_ln_bf16  hmm_op_qkv_attention_bf16 on xb / wf / c2 with the normalisation in the kernel. */
-int hmm_op_rowstat_bf16(const uint16_t* xb_dev, float* rs_dev, int rows, int dim, float eps, hmm_stream_t stream);
-int hmm_op_fold_ln_weights(const float* w0_dev, const float* gamma_dev, const float* beta_dev, const float* bias_dev,
-                           uint16_t* wf_dev, float* c1_dev, float* c2_dev, int n, int dim, hmm_stream_t stream);
-int hmm_op_gemm_bf16_ln(const uint16_t* a_dev, const uint16_t* wf_dev, const float* c2_dev, uint16_t* c_dev, int M, int N, int K,
-                        int gelu, const float* rs_dev, int rs_stride, const float* c1_dev, int tile, hmm_stream_t stream);
-int hmm_op_gemm_bf16_resid_xb(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev, float* c_dev,
-                              uint16_t* xb_dev, float* part_dev, int M, int N, int K, int tile, hmm_stream_t stream);
-int hmm_op_rowstat_finalize(const float* part_dev, float* rs_dev, int rows, int dim, float eps, hmm_stream_t stream);
-int hmm_op_qkv_attention_ln_bf16(const uint16_t* xb_dev, const uint16_t* wf_dev, const float* c2_dev,
-                                 const uint16_t* qkv_cls_dev, uint16_t* out_dev, int n_img, const float* rs_dev,
-                                 const float* c1_dev, hmm_stream_t stream);
 /* Causal variant (text tower): key j is visible to query i iff j <= i; no bias_kv. */
 int hmm_op_attention_causal_bf16(const uint16_t* qkv_dev, uint16_t* out_dev, int batch, int tokens,
                                  int heads, int head_dim, hmm_stream_t stream);

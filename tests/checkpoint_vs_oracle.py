@@ -4,7 +4,7 @@
     python tests/checkpoint_vs_oracle.py /path/to/imagebind_huge.pth [--towers vision audio text] [--depth N]
 
 Reports, per tower that loaded cleanly, the cosine between the HIP tower's embeddings and oracle/imagebind_oracle.py's
-(tolerance of the parity tests: >= 1 - 2e-4).  With a real imagebind_huge.pth this is the run that can retire the
+(tolerance of the parity tests: >= 1 - 5e-5).  With a real imagebind_huge.pth this is the run that can retire the
 encoder oracle's "parity unpinned" caveat.  Lives under tests/ because it uses the oracle."""
 import json
 import os
@@ -30,7 +30,7 @@ def main():
         for t in towers:
             cos = torch.nn.functional.cosine_similarity(emb[t], want[t], dim=1)
             report[t]["cos_vs_fp32_oracle"] = [round(float(c), 7) for c in cos]
-            ok &= bool((1 - cos).max() <= 2e-4)
+            ok &= bool((1 - cos).max() <= 5e-5)
     report["ok"] = bool(ok)
     print(json.dumps(report, indent=1))
     sys.exit(0 if ok else 1)

@@ -35,6 +35,32 @@ def test_fast_writer_equals_json_dumps_indent_2():
     assert es.event_json_text(odd, fast=True) == json.dumps(es.event_to_dict(odd), indent=2)
 
 
+class _DictEvent:
+    """An event whose to_dict() returns an arbitrary dict: the fast writer must not trust what it finds in it."""
+
+    def __init__(self, d):
+        self._d = d
+
+    def to_dict(self):
+        return self._d
+
+
+def test_fast_writer_checks_every_row_and_cannot_be_fooled_by_its_own_placeholder(monkeypatch):
+    base = es.event_to_dict(recipes.event_case())
+    rows = [[0.5, 1.5], [2.5, 3.5], [4.5, 5.5]]
+    for bad_middle in ([2.5, "a, b"], [2.5, [1.0, 2.0]], [2.5, 3], [2.5, True]):        # a string with ", ", a nested list, an int, a bool
+        d = dict(base, features={"vision": [rows[0], bad_middle, rows[2]]})
+        assert es.event_json_text(_DictEvent(d), fast=True) == json.dumps(d, indent=2)
+    # a string equal to the placeholder of matrix 0, earlier in the dict than the real hole: the writer must notice
+    class _Fixed:
+        hex = "0" * 32
+    monkeypatch.setattr(es.uuid, "uuid4", lambda: _Fixed)
+    token = "@@hmm_matrix_0_" + "0" * 32 + "@@"
+    d = dict(base, features={"vision": rows})
+    d = {"summary_first": token, **d}
+    assert es.event_json_text(_DictEvent(d), fast=True) == json.dumps(d, indent=2)
+
+
 def test_json_round_trip_is_exact_in_fp32():
     case = recipes.event_case()
     feats, times = es.parse_event_features(GOLD)

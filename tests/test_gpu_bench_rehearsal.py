@@ -16,7 +16,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 def test_two_rank_rehearsal_prints_a_complete_line():
     env = dict(os.environ, HMM_BENCH_REHEARSAL="1")
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--scan-strong"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

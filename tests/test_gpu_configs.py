@@ -62,6 +62,32 @@ def test_cfg5_two_rank_rehearsal_reproduces_the_one_gpu_result_bitwise(cfg5_one_
     assert c["gathered_embeddings_sha256"] == c1["gathered_embeddings_sha256"]  # 7 x 256 + 8 per rank vs 14 x 256 + 16
 
 
+def test_cfg5_eight_rank_rehearsal_reproduces_the_one_gpu_result_bitwise(cfg5_one_gpu):
+    """The shape the driver's 8-GPU run has: 8 ranks x 450 frames (256 + 194 per rank through the tower), one all-gather of
+    (450,1024) per rank, selection on (3600,1024) on every rank.  Eight processes on one GPU over gloo."""
+    d = _bench(["--workload", "cfg5", "--gpus", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-scan"],
+               env={"HMM_BENCH_REHEARSAL": "1"})
+    c, c1 = d["config"], cfg5_one_gpu["config"]
+    assert d["n_gpus"] == 8 and "rehearsal" in d and c["frames_per_rank"] == [450] * 8 and c["all_gather_bytes_per_rank"] == 450 * 4096
+    assert d["all_reduced_rank_count"] == 8 and [r["rank"] for r in d["ranks"]] == list(range(8))
+    assert c["kept_equal_cpu_oracle_on_gathered_matrix"] is True
+    assert c["kept_indices_sha256"] == c1["kept_indices_sha256"]
+    assert c["gathered_embeddings_sha256"] == c1["gathered_embeddings_sha256"]
+    print(f"8-rank rehearsal: startup {d['startup_s']} s on rank 0, step {d['ms_per_step']} ms (eight ranks sharing one GPU)")
+
+
+def test_cfg5_ragged_shards_eight_ranks_equal_one_gpu_bitwise():
+    """3601 frames do not divide by 8: shard_bounds gives 7 x 451 + 444, the all-gather pads to 451 rows and trims."""
+    one = _bench(["--workload", "cfg5", "--cfg5-frames", "3601", "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    d = _bench(["--workload", "cfg5", "--cfg5-frames", "3601", "--gpus", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                "--no-scan"], env={"HMM_BENCH_REHEARSAL": "1"})
+    c, c1 = d["config"], one["config"]
+    assert c["frames_per_rank"] == [451] * 7 + [444] and c["all_gather_bytes_per_rank"] == 451 * 4096
+    assert c["kept_equal_cpu_oracle_on_gathered_matrix"] is True and c1["kept_equal_cpu_oracle_on_gathered_matrix"] is True
+    assert c["kept_indices_sha256"] == c1["kept_indices_sha256"]
+    assert c["gathered_embeddings_sha256"] == c1["gathered_embeddings_sha256"]
+
+
 def test_cfg1_frame_buffer_chain_at_full_depth():
     import bench
     from hippomm_amd import consolidation
@@ -89,8 +115,8 @@ def test_cfg1_frame_buffer_chain_at_full_depth():
     st = {k: v.detach().float().cpu() for k, v in sd.items()}
     ref = ib.vision_forward(frames.cpu(), st)                                # fp32 oracle tower, all 32 blocks
     cos = torch.nn.functional.cosine_similarity(feats.cpu(), ref, dim=1)
-    assert (1 - cos).max().item() <= 2e-4, cos.min().item()
-    assert (feats.cpu() - ref).abs().max().item() <= 2e-2
+    assert (1 - cos).max().item() <= 5e-5, cos.min().item()
+    assert (feats.cpu() - ref).abs().max().item() <= 2e-3
     # fed the ORACLE's fp32 embeddings the selection keeps the same frames unless a comparison sits within the bf16
     # embedding error of the threshold (north_star: bit-exact indices are defined on identical feature matrices)
     if min(evaluated_margin(emb, 0.9), evaluated_margin(ref.numpy(), 0.9)) > 1e-3:

@@ -2,7 +2,7 @@
 seeded synthetic weights.  The oracle itself is unpinned by the reference (see its header).
 
 Tolerance (stated, per north_star): bf16 operands / fp32 accumulation / fp32 residual stream vs
-the all-fp32 oracle -- cosine(emb_gpu, emb_oracle) >= 1 - 2e-4 and max |diff| <= 2e-2 on unit
+the all-fp32 oracle -- cosine(emb_gpu, emb_oracle) >= 1 - 5e-5 and max |diff| <= 2e-3 on unit
 vectors (x20 for audio), measured margins are printed."""
 import numpy as np
 import pytest
@@ -12,8 +12,8 @@ from oracle import imagebind_oracle as ib
 
 pytestmark = pytest.mark.gpu
 
-COS_TOL = 2e-4
-ABS_TOL = 2e-2
+COS_TOL = 5e-5
+ABS_TOL = 2e-3
 
 
 def _check(got: torch.Tensor, want: torch.Tensor, scale: float = 1.0, what: str = ""):

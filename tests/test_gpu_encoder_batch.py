@@ -20,8 +20,8 @@ from oracle import imagebind_oracle as ib
 
 pytestmark = pytest.mark.gpu
 
-COS_TOL = 2e-4
-ABS_TOL = 2e-2
+COS_TOL = 5e-5
+ABS_TOL = 2e-3
 
 
 def _check(got, want, scale=1.0, what=""):
