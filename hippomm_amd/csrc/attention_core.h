@@ -41,13 +41,23 @@ struct AttnCfg {
 
 constexpr int kAttnWaves = 8;
 
+// probe build: in-kernel stamps of the attention phase (tools/fused_stamp_probe.py); nothing in the product library
+#ifdef HMM_PROBE
+#define HMM_ATTN_PROBE_PARAM , unsigned long long* attn_stamps = nullptr
+#define HMM_ATTN_STAMP(slot) \
+    if (attn_stamps && threadIdx.x == 0) attn_stamps[(slot)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define HMM_ATTN_PROBE_PARAM
+#define HMM_ATTN_STAMP(slot)
+#endif
+
 // k_lds / v_lds: the images (rows >= Lk zero-filled); part: C::X_BYTES of LDS scratch; load_q(row, ks) -> the bf16x8
 // fragment d = 16 ks + 8 hh .. + 7 of query `row` (row < T) for this lane's hh = lane >> 5; qf: the fragments of query
 // tile `wave`, preloaded by the caller; out_head = out + sample * T * D + head * DH.  Ends with the results stored.
 template <int DH, int NKT, class QLoad>
 __device__ __forceinline__ void attention_core(const char* k_lds, const char* v_lds, float* part, QLoad load_q,
                                                bf16x8 (&qf)[AttnCfg<DH, NKT>::KS], bf16_t* __restrict__ out_head,
-                                               int T, int Lk, int D, float scale_log2e, bool causal) {
+                                               int T, int Lk, int D, float scale_log2e, bool causal HMM_ATTN_PROBE_PARAM) {
     using C = AttnCfg<DH, NKT>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -200,6 +210,7 @@ __device__ __forceinline__ void attention_core(const char* k_lds, const char* v_
             }
     }
 
+    HMM_ATTN_STAMP(3)
     if (coop) {
         const int xq = T - 1;                                  // the extra query row: every column of the B operand = this query
 #pragma unroll

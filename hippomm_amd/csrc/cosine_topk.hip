@@ -15,29 +15,11 @@
 // on ties, NaN first"; 0 is the padding key (no valid row maps to it).
 #include "hmm_common.h"
 #include "topk_tournament.h"
+#include "cosine_topk_shared.h"
 
 namespace hmm {
 
-constexpr int kChunk = 4096;      // keys sorted per block
 constexpr int kFastK = 1024;      // chunk-tournament path handles k <= kFastK
-constexpr int kScanBlocks = kNumCU * 8;
-
-template <bool NT>
-__device__ __forceinline__ float4 ld16(const float4* p) {
-    if constexpr (NT) {
-        f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-        return make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-        return *p;
-    }
-}
-
-__device__ __forceinline__ void fma4(float& dot, float& ss, const float4& x, const float4& q) {
-    dot = fmaf(x.x, q.x, dot); ss = fmaf(x.x, x.x, ss);
-    dot = fmaf(x.y, q.y, dot); ss = fmaf(x.y, x.y, ss);
-    dot = fmaf(x.z, q.z, dot); ss = fmaf(x.z, x.z, ss);
-    dot = fmaf(x.w, q.w, dot); ss = fmaf(x.w, x.w, ss);
-}
 
 // sims[r] = dot(store[r], q) / (||store[r]|| * ||q||)     (vector_ops.py:178-182)
 template <bool NT>
@@ -123,12 +105,6 @@ __device__ __forceinline__ void bitonic_sort_desc_rt(uint64_t* s, int n2) {
     }
 }
 
-__device__ __forceinline__ int pow2_at_least(int n, int lo) {
-    int p = lo;
-    while (p < n) p <<= 1;
-    return p;
-}
-
 // Each block sorts one chunk and writes its best `k` keys (0-padded) to out[blockIdx.x*k ..].
 template <bool FROM_SIMS>
 __global__ __launch_bounds__(1024) void topk_chunk_kernel(const void* __restrict__ in, int64_t n_in,
@@ -160,14 +136,16 @@ __global__ __launch_bounds__(1024) void topk_chunk_kernel(const void* __restrict
 // end, the block sorts it and keeps its best k, which go to out[blockIdx.x*k ..] (0-padded).  Nothing
 // but k keys per block (8*k B) is written, and the follow-up passes see blocks*k keys instead of N.
 constexpr int kFusedK = 128;
-constexpr int kFusedCap = 1024;
 
+// run_if (may be null): the kernel returns at once when *run_if == 0 -- the exact scan as the conditional fallback of the
+// bf16-prefilter path (cosine_topk_prefilter.hip).
 template <bool NT>
 __global__ __launch_bounds__(256) void scan_topk_kernel(const float4* __restrict__ store, int64_t n_rows,
                                                         const float4* __restrict__ query, int k,
-                                                        uint64_t* __restrict__ out) {
+                                                        uint64_t* __restrict__ out, const int* __restrict__ run_if) {
     __shared__ uint64_t cand[kFusedCap];
     __shared__ int count;
+    if (run_if != nullptr && *run_if == 0) return;             // workgroup-uniform
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -236,8 +214,9 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const float4* __restrict
 __global__ __launch_bounds__(1024) void topk_final_kernel(const uint64_t* __restrict__ cand, int n_blocks, int k,
                                                           int64_t n_waves, uint64_t* __restrict__ keys_out, int k_pad,
                                                           int64_t* __restrict__ idx_out, float* __restrict__ sim_out,
-                                                          int32_t* __restrict__ n_out) {
+                                                          int32_t* __restrict__ n_out, const int* __restrict__ run_if) {
     __shared__ uint64_t mx[kScanBlocks];       // block maxima
+    if (run_if != nullptr && *run_if == 0) return;
     __shared__ uint64_t s[kChunk];             // keys of the winning blocks
     const int tid = threadIdx.x;
     const int n2 = pow2_at_least(n_blocks, 64);
@@ -427,7 +406,7 @@ struct ScanOut {                 // where the result of run_scan lives
 
 // Runs scan + selection up to (not including) the final decode / key copy.
 static int run_scan(const float* store, int64_t n, int dim, const float* query, int k,
-                    void* ws, size_t ws_bytes, hipStream_t st, ScanOut* out) {
+                    void* ws, size_t ws_bytes, hipStream_t st, ScanOut* out, const int* run_if = nullptr) {
     const uint64_t** best = &out->best;
     int* k_eff = &out->k_eff;
     out->fused = false;
@@ -452,13 +431,14 @@ static int run_scan(const float* store, int64_t n, int dim, const float* query, 
     if (!p.full_sort && n > kChunk && p.k_eff <= kFusedK) {
         // fused: the streaming kernel emits k candidates per block; reduce blocks*k keys by chunk sorts
         scan_topk_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n,
-                                                       reinterpret_cast<const float4*>(query), p.k_eff, buf_a);
+                                                       reinterpret_cast<const float4*>(query), p.k_eff, buf_a, run_if);
         HMM_LAUNCH_CHECK();
         if ((int64_t)p.k_eff * p.k_eff <= kChunk && blocks <= kScanBlocks) {     // one-kernel finish
             out->fused = true; out->cand = buf_a; out->n_blocks = blocks; out->n_waves = (int64_t)blocks * 4;
             out->best = nullptr;
             return HMM_OK;
         }
+        HMM_REQUIRE(run_if == nullptr, HMM_E_INVALID, "cosine_topk: the conditional scan needs k * k <= %d", kChunk);
         int64_t count = (int64_t)blocks * p.k_eff;
         uint64_t* cur = buf_a;
         uint64_t* nxt = buf_b;
@@ -474,6 +454,7 @@ static int run_scan(const float* store, int64_t n, int dim, const float* query, 
         return HMM_OK;
     }
 
+    HMM_REQUIRE(run_if == nullptr, HMM_E_INVALID, "cosine_topk: the conditional scan needs n > %d and k <= %d", kChunk, kFusedK);
     scan_sims_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n,
                                                    reinterpret_cast<const float4*>(query), sims);
     HMM_LAUNCH_CHECK();
@@ -507,6 +488,18 @@ static int run_scan(const float* store, int64_t n, int dim, const float* query, 
     return HMM_OK;
 }
 
+// hmm_cosine_topk executed only when *run_if != 0 on the device (both kernels return at once otherwise); n > 4096 and k <= 64.
+int cosine_topk_if(const int* run_if, const float* store, int64_t n, const float* query, int k, int64_t* idx_out, float* sim_out,
+                   int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t st) {
+    ScanOut r{};
+    int rc = run_scan(store, n, HMM_FEATURE_DIM, query, k, ws, ws_bytes, st, &r, run_if);
+    if (rc != HMM_OK) return rc;
+    HMM_REQUIRE(r.fused, HMM_E_INVALID, "cosine_topk_if: not the fused path");
+    topk_final_kernel<<<1, 1024, 0, st>>>(r.cand, r.n_blocks, r.k_eff, r.n_waves, nullptr, 0, idx_out, sim_out, n_out, run_if);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+
 }  // namespace hmm
 
 using namespace hmm;
@@ -526,7 +519,7 @@ extern "C" int hmm_cosine_topk(const float* store_dev, int64_t n_rows, int dim, 
     if (rc != HMM_OK) return rc;
     if (r.fused) {
         topk_final_kernel<<<1, 1024, 0, st>>>(r.cand, r.n_blocks, r.k_eff, r.n_waves, nullptr, 0, idx_out_dev, sim_out_dev,
-                                              n_out_dev);
+                                              n_out_dev, nullptr);
     } else {
         decode_kernel<<<(r.k_eff + 255) / 256, 256, 0, st>>>(r.best, r.k_eff, idx_out_dev, sim_out_dev, n_out_dev);
     }
@@ -544,7 +537,7 @@ extern "C" int hmm_cosine_topk_keys(const float* store_dev, int64_t n_rows, int 
     if (rc != HMM_OK) return rc;
     if (r.fused) {
         topk_final_kernel<<<1, 1024, 0, st>>>(r.cand, r.n_blocks, r.k_eff, r.n_waves, keys_out_dev, k, nullptr, nullptr,
-                                              nullptr);
+                                              nullptr, nullptr);
     } else {
         copy_keys_kernel<<<(k + 255) / 256, 256, 0, st>>>(r.best, r.k_eff, keys_out_dev, k);
     }
@@ -586,7 +579,7 @@ extern "C" int hmm_op_scan_topk_only(const float* store_dev, int64_t n_rows, con
     int blocks = (int)((waves_needed + 3) / 4);
     if (blocks > kScanBlocks) blocks = kScanBlocks;
     scan_topk_kernel<true><<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
-        reinterpret_cast<const float4*>(store_dev), n_rows, reinterpret_cast<const float4*>(query_dev), k, cand_dev);
+        reinterpret_cast<const float4*>(store_dev), n_rows, reinterpret_cast<const float4*>(query_dev), k, cand_dev, nullptr);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }

@@ -1,0 +1,331 @@
+// feature_search scan through a bf16 SHADOW of the store, exact by construction ("if a bf16 shadow store is also
+// offered, report it separately against 2 048 000 000 B").  Same result as hmm_cosine_topk -- the same rows, the same fp32
+// similarities bit for bit (reference hippomm/utils/vector_ops.py:178-186) -- for half the bytes streamed:
+//
+//   shadow   row r = bf16(x_r / ||x_r||)  (round to nearest even; a zero-norm or non-finite row becomes NaN), 2048 B per row,
+//            built once per store by hmm_shadow_store_build;
+//   pass 1   prefilter_topk_kernel streams the shadow: s~_r = dot(shadow_r, q) / ||q|| in fp32, block-local top-k of the s~ keys
+//            exactly as scan_topk_kernel keeps them (cosine_topk.hip);
+//   pass 2   prefilter_final_kernel (one workgroup): t = the k-th largest s~ over all blocks; every row whose exact similarity
+//            can be among the k largest has s~_r >= t - 2 eps (below); those rows are re-scored on the fp32 store with the
+//            arithmetic of scan_topk_kernel (exact_row_sim: same loads, same fma order, same wave reduction, same division) and
+//            the k best of them are the answer.
+//   Error bound.  bf16 has an 8-bit significand: x~ = x (1 + d), |d| <= 2^-8, so |dot(x~, q) - dot(x, q)| <= 2^-8 sum |x_i q_i|
+//            <= 2^-8 ||x|| ||q||, i.e. |s~ - s| <= 2^-8 (1 + 2^-8) + fp32 summation noise (~3e-6 for both kernels) < eps = 0.0040.
+//            If row r is in the exact top-k then s_r >= the k-th largest s >= t - eps (k rows have s >= s~ - eps >= t - eps), hence
+//            s~_r >= t - 2 eps: r is a candidate.  A NaN s~ (zero-norm row, NaN query) ranks first, as NaN similarities do.
+//   Fallback.  The candidate set is complete only if no block's list is saturated above the threshold (its k-th entry >= t - 2 eps
+//            means the block may have dropped candidates) and fits the re-scoring buffer; otherwise pass 2 raises a flag and the
+//            exact scan (scan_topk_kernel + topk_final_kernel, conditional on that flag) produces the answer.  Either way the
+//            outputs are those of hmm_cosine_topk.  Stores of many near-ties (thousands of rows within 0.8 % of the k-th best)
+//            take the fallback: 0.3 ms wasted; random or video-like stores do not.
+#include "hmm_common.h"
+#include "topk_tournament.h"
+#include "cosine_topk_shared.h"
+
+namespace hmm {
+
+constexpr float kPrefilterEps = 0.0040f;
+constexpr int kPrefilterCap = 1024;           // candidate rows pass 2 re-scores itself (16 waves)
+constexpr int kPrefilterMaxK = 64;
+
+// ---- shadow build: one wave per row ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shadow_build_kernel(const float4* __restrict__ store, int64_t n_rows,
+                                                           uint4* __restrict__ shadow) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < n_rows; r += n_waves) {
+        // lane l owns elements 8 l .. 8 l + 7 and 512 + 8 l .. + 7 (two 32-B pieces in, two 16-B pieces out)
+        const float4* p = store + r * 256;
+        float4 v[4] = {p[2 * lane], p[2 * lane + 1], p[128 + 2 * lane], p[128 + 2 * lane + 1]};
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ss = fmaf(v[i].x, v[i].x, ss); ss = fmaf(v[i].y, v[i].y, ss);
+            ss = fmaf(v[i].z, v[i].z, ss); ss = fmaf(v[i].w, v[i].w, ss);
+        }
+        ss = wave_sum(ss);
+        float inv = 1.0f / sqrtf(ss);
+        if (!(ss > 0.f) || !(ss < INFINITY)) inv = __uint_as_float(0x7FC00000u);      // zero / non-finite norm: the row is NaN
+        uint4 o[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 a = v[2 * h], b = v[2 * h + 1];
+            bf16x8 t = {(bf16_t)(a.x * inv), (bf16_t)(a.y * inv), (bf16_t)(a.z * inv), (bf16_t)(a.w * inv),
+                        (bf16_t)(b.x * inv), (bf16_t)(b.y * inv), (bf16_t)(b.z * inv), (bf16_t)(b.w * inv)};
+            o[h] = __builtin_bit_cast(uint4, t);
+        }
+        uint4* q = shadow + r * 128;
+        q[lane] = o[0];
+        q[64 + lane] = o[1];
+    }
+}
+
+__device__ __forceinline__ float dot8_bf16(const uint4& x, const float4& qa, const float4& qb, float acc) {
+    // bf16 -> fp32 is a 16-bit shift: low half << 16, high half masked
+    acc = fmaf(__uint_as_float(x.x << 16), qa.x, acc); acc = fmaf(__uint_as_float(x.x & 0xFFFF0000u), qa.y, acc);
+    acc = fmaf(__uint_as_float(x.y << 16), qa.z, acc); acc = fmaf(__uint_as_float(x.y & 0xFFFF0000u), qa.w, acc);
+    acc = fmaf(__uint_as_float(x.z << 16), qb.x, acc); acc = fmaf(__uint_as_float(x.z & 0xFFFF0000u), qb.y, acc);
+    acc = fmaf(__uint_as_float(x.w << 16), qb.z, acc); acc = fmaf(__uint_as_float(x.w & 0xFFFF0000u), qb.w, acc);
+    return acc;
+}
+
+// ---- pass 1: stream the shadow, block-local top-k of the approximate keys ------------------------------------------------------
+// Rows are dealt four at a time, wave after wave (row r belongs to wave (r / 4) % n_waves), so neighbouring rows -- near-duplicate
+// frames of a video -- spread over the blocks instead of saturating one block's list.  8 x 16 B in flight per lane.
+__global__ __launch_bounds__(256) void prefilter_topk_kernel(const uint4* __restrict__ shadow, int64_t n_rows,
+                                                             const float4* __restrict__ query, int k,
+                                                             uint64_t* __restrict__ out) {
+    __shared__ uint64_t cand[kFusedCap];
+    __shared__ int count;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    if (threadIdx.x == 0) count = 0;
+    // query elements of this lane, in the shadow's piece order, and 1 / ||q|| exactly as the exact kernels take ||q||
+    float4 q[4];
+    float qs = 0.f;
+    {
+        float4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[j] = query[j * 64 + lane];
+            qs = fmaf(t[j].x, t[j].x, qs); qs = fmaf(t[j].y, t[j].y, qs);
+            qs = fmaf(t[j].z, t[j].z, qs); qs = fmaf(t[j].w, t[j].w, qs);
+        }
+        q[0] = query[2 * lane]; q[1] = query[2 * lane + 1]; q[2] = query[128 + 2 * lane]; q[3] = query[128 + 2 * lane + 1];
+    }
+    const float inv_qlen = 1.0f / sqrtf(wave_sum(qs));
+    __syncthreads();
+
+    const int64_t iters = (n_rows + n_waves * 4 - 1) / (n_waves * 4);
+    const int compact_every = (kFusedCap - k) / 16;                          // 16 rows per block per iteration
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t r = wave * 4 + it * n_waves * 4;
+        const int have = r >= n_rows ? 0 : (n_rows - r >= 4 ? 4 : (int)(n_rows - r));      // wave-uniform
+        if (have) {
+            uint4 x[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4* p = shadow + (r + (i < have ? i : 0)) * 128 + lane;
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+                const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 64));
+                x[i][0] = make_uint4(a[0], a[1], a[2], a[3]);
+                x[i][1] = make_uint4(b[0], b[1], b[2], b[3]);
+            }
+            float d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = dot8_bf16(x[i][1], q[2], q[3], dot8_bf16(x[i][0], q[0], q[1], 0.f));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = wave_sum(d[i]);
+            if (lane == 0) {
+                const int pos = atomicAdd(&count, have);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < have) cand[pos + i] = ((uint64_t)order_bits(d[i] * inv_qlen) << 32) | (uint64_t)(uint32_t)(r + i);
+            }
+        }
+        if ((it + 1) % compact_every == 0 || it + 1 == iters) {              // block-uniform
+            __syncthreads();
+            const int n = count;
+            const int n2 = pow2_at_least(n, 64);
+            for (int t = n + threadIdx.x; t < n2; t += 256) cand[t] = 0ull;
+            __syncthreads();
+            top64_desc(cand, n2);                                            // k <= 64 on this path
+            if (threadIdx.x == 0) count = n < k ? n : k;
+            __syncthreads();
+        }
+    }
+    const int n = count;
+    for (int t = threadIdx.x; t < k; t += 256) out[(int64_t)blockIdx.x * k + t] = t < n ? cand[t] : 0ull;
+}
+
+// ---- pass 2: threshold, candidates, exact re-score, answer (or the fallback flag) -------------------------------------------
+// lists: n_blocks x kk keys (kk >= k entries per block, sorted descending, 0-padded).
+__global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* __restrict__ lists, int n_blocks, int k, int kk,
+                                                               int64_t n_waves, const float4* __restrict__ store,
+                                                               const float4* __restrict__ query,
+                                                               int64_t* __restrict__ idx_out, float* __restrict__ sim_out,
+                                                               int32_t* __restrict__ n_out, int* __restrict__ fallback,
+                                                               int* __restrict__ stats /* [2]: candidates, saturated lists */) {
+    __shared__ uint64_t mx[kScanBlocks];
+    __shared__ uint64_t s[kChunk];
+    __shared__ uint32_t cand_row[kPrefilterCap];
+    __shared__ uint16_t hot[kScanBlocks];
+    __shared__ int n_cand, n_sat, n_hot;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { n_cand = 0; n_sat = 0; n_hot = 0; }
+    // the k-th largest approximate key: the k lists with the largest maxima hold it (see topk_final_kernel)
+    const int n2 = pow2_at_least(n_blocks, 64);
+    uint64_t own[kScanBlocks / 1024];                                         // this thread's block maxima, kept for the hot-list pass
+#pragma unroll
+    for (int i = 0; i < kScanBlocks / 1024; ++i) {
+        const int t = tid + i * 1024;
+        own[i] = t < n_blocks ? lists[(int64_t)t * kk] : 0ull;
+        if (t < n2) mx[t] = own[i];
+    }
+    __syncthreads();
+    top64_desc(mx, n2);
+    const int n_win = n_blocks < k ? n_blocks : k;
+    const int m2 = pow2_at_least(n_win * kk, 64);
+    for (int t = tid; t < m2; t += 1024) {
+        uint64_t key = 0ull;
+        if (t < n_win * kk) {
+            const uint64_t top = mx[t / kk];
+            if (top != 0ull) {
+                const int64_t row = (int64_t)(top & 0xFFFFFFFFull);
+                const int blk = (int)(((row >> 2) % n_waves) >> 2);           // rows are dealt four per wave
+                key = lists[(int64_t)blk * kk + (t % kk)];
+            }
+        }
+        s[t] = key;
+    }
+    __syncthreads();
+    top64_desc(s, m2);
+    const uint64_t kth = s[k - 1];                                            // 0 = fewer than k rows in all (launcher excludes it)
+    const float t_lo = order_bits_inverse((uint32_t)(kth >> 32)) - 2.0f * kPrefilterEps;
+    const uint32_t thr = order_bits(t_lo);                                    // NaN k-th -> 0xFFFFFFFF: only NaN rows pass
+    __syncthreads();
+    // lists that can hold a candidate: those whose maximum reaches the threshold
+#pragma unroll
+    for (int i = 0; i < kScanBlocks / 1024; ++i)
+        if (own[i] != 0ull && (uint32_t)(own[i] >> 32) >= thr) hot[atomicAdd(&n_hot, 1)] = (uint16_t)(tid + i * 1024);
+    __syncthreads();
+    // one wave per hot list, one entry per lane: every entry at or above the threshold is a candidate; a list whose LAST entry
+    // passes may have dropped some (saturated)
+    for (int h = wave; h < n_hot; h += 16) {
+        const int b = hot[h];
+        const uint64_t key = lane < kk ? lists[(int64_t)b * kk + lane] : 0ull;
+        const bool pass = key != 0ull && (uint32_t)(key >> 32) >= thr;
+        const unsigned long long mask = __ballot(pass);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&n_cand, __popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (pass) {
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < kPrefilterCap) cand_row[pos] = (uint32_t)(key & 0xFFFFFFFFull);
+            if (lane == kk - 1) atomicAdd(&n_sat, 1);
+        }
+    }
+    __syncthreads();
+    const int m = n_cand;
+    const bool fall = kth == 0ull || n_sat > 0 || m > kPrefilterCap;
+    if (tid == 0) {
+        *fallback = fall ? 1 : 0;
+        if (stats) { stats[0] = m; stats[1] = n_sat; }
+    }
+    if (fall) return;                                                         // block-uniform: the exact scan answers
+    // exact re-score: one wave per candidate row, the arithmetic of scan_topk_kernel
+    float4 q[4];
+    float qs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        q[j] = query[j * 64 + lane];
+        qs = fmaf(q[j].x, q[j].x, qs); qs = fmaf(q[j].y, q[j].y, qs);
+        qs = fmaf(q[j].z, q[j].z, qs); qs = fmaf(q[j].w, q[j].w, qs);
+    }
+    const float q_len = sqrtf(wave_sum(qs));
+    const int m_pad = pow2_at_least(m, 64);
+    for (int c = wave; c < m_pad; c += 16) {
+        uint64_t key = 0ull;
+        if (c < m) {
+            const uint32_t row = cand_row[c];
+            const float sim = exact_row_sim(store + (int64_t)row * 256 + lane, q, q_len);
+            key = ((uint64_t)order_bits(sim) << 32) | (uint64_t)row;
+        }
+        if (lane == 0) s[c] = key;
+    }
+    __syncthreads();
+    top64_desc(s, m_pad);
+    if (tid == 0 && n_out) *n_out = k;
+    for (int t = tid; t < k; t += 1024) {
+        idx_out[t] = (int64_t)(s[t] & 0xFFFFFFFFull);
+        sim_out[t] = order_bits_inverse((uint32_t)(s[t] >> 32));
+    }
+}
+
+// Entries a block keeps: at least twice k and at least 16, so that a handful of near-ties inside one block (k = 1: ANY second
+// candidate) does not saturate its list; 64 at most (the tournament's width).
+static int prefilter_list_len(int k) {
+    int kk = 2 * k < 16 ? 16 : 2 * k;
+    return kk > kPrefilterMaxK ? kPrefilterMaxK : kk;
+}
+
+struct PrefilterPlan { size_t off_exact, off_lists, off_flag, total; int blocks; };
+
+static PrefilterPlan prefilter_plan(int64_t n, int k) {
+    PrefilterPlan p{};
+    p.off_exact = 0;
+    const size_t exact = hmm_cosine_topk_workspace_bytes(n, k);
+    p.off_lists = align_up(exact, 256);
+    int64_t waves_needed = (n + 3) / 4;
+    int blocks = (int)((waves_needed + 3) / 4);
+    p.blocks = blocks > kScanBlocks ? kScanBlocks : blocks;
+    p.off_flag = p.off_lists + align_up((size_t)kScanBlocks * (size_t)kPrefilterMaxK * 8, 256);
+    p.total = p.off_flag + 256;
+    return p;
+}
+
+}  // namespace hmm
+
+using namespace hmm;
+
+extern "C" size_t hmm_shadow_store_bytes(int64_t n_rows) {
+    return n_rows < 1 ? 0 : (size_t)n_rows * 2048;
+}
+
+extern "C" int hmm_shadow_store_build(const float* store_dev, int64_t n_rows, int dim, void* shadow_dev, size_t shadow_bytes,
+                                      hmm_stream_t stream) {
+    HMM_REQUIRE(dim == HMM_FEATURE_DIM, HMM_E_INVALID, "shadow_store_build: dim must be %d, got %d", HMM_FEATURE_DIM, dim);
+    HMM_REQUIRE(store_dev && shadow_dev && n_rows >= 1, HMM_E_INVALID, "shadow_store_build: bad arguments");
+    HMM_REQUIRE(((uintptr_t)store_dev & 15) == 0 && ((uintptr_t)shadow_dev & 15) == 0, HMM_E_INVALID,
+                "shadow_store_build: store / shadow must be 16-byte aligned");
+    HMM_REQUIRE(shadow_bytes >= hmm_shadow_store_bytes(n_rows), HMM_E_WORKSPACE, "shadow_store_build: shadow buffer %zu < %zu",
+                shadow_bytes, hmm_shadow_store_bytes(n_rows));
+    int64_t blocks = (n_rows + 3) / 4;
+    if (blocks > kScanBlocks * 4) blocks = kScanBlocks * 4;
+    shadow_build_kernel<<<(unsigned)blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
+        reinterpret_cast<const float4*>(store_dev), n_rows, static_cast<uint4*>(shadow_dev));
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+
+extern "C" size_t hmm_cosine_topk_prefilter_workspace_bytes(int64_t n_rows, int k) {
+    if (n_rows < 1 || k < 1) return 0;
+    return prefilter_plan(n_rows, k).total;
+}
+
+extern "C" int hmm_cosine_topk_prefilter(const float* store_dev, const void* shadow_dev, int64_t n_rows, int dim,
+                                         const float* query_dev, int k, int64_t* idx_out_dev, float* sim_out_dev,
+                                         int32_t* n_out_dev, int32_t* stats_out_dev, void* workspace_dev, size_t workspace_bytes,
+                                         hmm_stream_t stream) {
+    HMM_REQUIRE(dim == HMM_FEATURE_DIM, HMM_E_INVALID, "cosine_topk_prefilter: dim must be %d, got %d", HMM_FEATURE_DIM, dim);
+    HMM_REQUIRE(store_dev && shadow_dev && query_dev && idx_out_dev && sim_out_dev && workspace_dev, HMM_E_INVALID,
+                "cosine_topk_prefilter: null pointer");
+    HMM_REQUIRE(k >= 1, HMM_E_INVALID, "cosine_topk_prefilter: k must be >= 1, got %d", k);
+    HMM_REQUIRE(((uintptr_t)store_dev & 15) == 0 && ((uintptr_t)shadow_dev & 15) == 0 && ((uintptr_t)query_dev & 15) == 0,
+                HMM_E_INVALID, "cosine_topk_prefilter: store / shadow / query must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const PrefilterPlan p = prefilter_plan(n_rows, k);
+    HMM_REQUIRE(workspace_bytes >= p.total, HMM_E_WORKSPACE, "cosine_topk_prefilter: workspace %zu < required %zu", workspace_bytes,
+                p.total);
+    char* ws = static_cast<char*>(workspace_dev);
+    // Small stores, large k: the prefilter has nothing to win (or no list machinery): the exact scan is the whole call.
+    if (k > kPrefilterMaxK || n_rows < (int64_t)kChunk * 4 || n_rows <= k) {
+        if (stats_out_dev) HMM_HIP_CHECK(hipMemsetAsync(stats_out_dev, 0xFF, 2 * sizeof(int32_t), st));      // -1, -1: not used
+        return hmm_cosine_topk(store_dev, n_rows, dim, query_dev, k, idx_out_dev, sim_out_dev, n_out_dev, ws + p.off_exact,
+                               p.off_lists, stream);
+    }
+    uint64_t* lists = reinterpret_cast<uint64_t*>(ws + p.off_lists);
+    int* flag = reinterpret_cast<int*>(ws + p.off_flag);
+    const int kk = prefilter_list_len(k);
+    prefilter_topk_kernel<<<p.blocks, 256, 0, st>>>(static_cast<const uint4*>(shadow_dev), n_rows,
+                                                    reinterpret_cast<const float4*>(query_dev), kk, lists);
+    HMM_LAUNCH_CHECK();
+    prefilter_final_kernel<<<1, 1024, 0, st>>>(lists, p.blocks, k, kk, (int64_t)p.blocks * 4, reinterpret_cast<const float4*>(store_dev),
+                                               reinterpret_cast<const float4*>(query_dev), idx_out_dev, sim_out_dev, n_out_dev, flag,
+                                               stats_out_dev);
+    HMM_LAUNCH_CHECK();
+    // the exact scan, executed only when the flag is up (both kernels return at once otherwise)
+    return cosine_topk_if(flag, store_dev, n_rows, query_dev, k, idx_out_dev, sim_out_dev, n_out_dev, ws + p.off_exact, p.off_lists, st);
+}

@@ -108,14 +108,17 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float*
 // memory latency per 64 columns of K when a workgroup is alone on its CU (few tiles: ~0.55 us per K-tile, the text tower's
 // fc2 at K = 4096 is 40 us whatever M).  STAGES > 2: a ring with STAGES - 1 K-tiles in flight behind a counted vmcnt, one
 // barrier per K-tile; same fragment reads and MFMA order, same bits.
-template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2>
+// KSUB > 1 ("deep K"): a ring stage holds KSUB consecutive K-tiles, so the barrier, the counted wait and the DMA issue are paid
+// once per KSUB x 64 columns of K -- for launches of few rows, where a workgroup is alone on its CU and every step is a chain
+// of latencies, not of MFMAs.  K / 64 must be a multiple of KSUB (the launcher checks).  Same MFMA order, same bits.
+template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2, int KSUB = 1>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     void* __restrict__ Cout, int M, int N, int K, int tiles_n) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
-    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, SUB = A_BYTES + W_BYTES, STAGE = KSUB * SUB;
     constexpr int A_PER_WAVE = (BM / 8) / NW, W_PER_WAVE = (BN / 8) / NW;
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "staging must divide evenly over waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -148,16 +151,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
         w_src[i] = W + (size_t)(n0 + row) * K + c * 8;
     }
 
-    auto stage = [&](int kt, int buf) {
-        char* base = smem + buf * STAGE;
+    auto stage = [&](int kg, int buf) {                  // the KSUB K-tiles of group kg into ring buffer `buf`
 #pragma unroll
-        for (int i = 0; i < A_PER_WAVE; ++i)
-            __builtin_amdgcn_global_load_lds(HMM_GLB_PTR(a_src[i] + kt * 64),
-                                             HMM_LDS_PTR(base + (wave + i * NW) * 1024), 16, 0, 0);
+        for (int sub = 0; sub < KSUB; ++sub) {
+            char* base = smem + buf * STAGE + sub * SUB;
+            const int kt = kg * KSUB + sub;
 #pragma unroll
-        for (int i = 0; i < W_PER_WAVE; ++i)
-            __builtin_amdgcn_global_load_lds(HMM_GLB_PTR(w_src[i] + kt * 64),
-                                             HMM_LDS_PTR(base + A_BYTES + (wave + i * NW) * 1024), 16, 0, 0);
+            for (int i = 0; i < A_PER_WAVE; ++i)
+                __builtin_amdgcn_global_load_lds(HMM_GLB_PTR(a_src[i] + kt * 64),
+                                                 HMM_LDS_PTR(base + (wave + i * NW) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < W_PER_WAVE; ++i)
+                __builtin_amdgcn_global_load_lds(HMM_GLB_PTR(w_src[i] + kt * 64),
+                                                 HMM_LDS_PTR(base + A_BYTES + (wave + i * NW) * 1024), 16, 0, 0);
+        }
     };
 
     // fragment read offsets: row = tile_row0 + 16*blk + (lane&15); chunk' = (4*kh + (lane>>4)) ^ ((row>>1)&7)
@@ -174,13 +181,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int KT = K / 64;
+    const int KT = K / (64 * KSUB);                      // ring steps (groups of KSUB K-tiles)
     // All fragment reads of the K-tile first, then the MFMAs in K order behind COUNTED waits: the second half's reads are in
     // flight under the first half's MFMAs (one exposed LDS latency per K-tile instead of two; with one wave per SIMD nothing else
     // hides it).  The reads are inline assembly because the compiler waits for lgkmcnt(0) before the first MFMA however the
     // loads are arranged; the empty asm statements tie each fragment to the wait in front of it (volatile asm keeps its order).
     const uint32_t lds0 = (uint32_t)(uintptr_t)HMM_LDS_PTR(smem);
-    auto compute = [&](int stage_off) {
+    auto compute_sub = [&](int stage_off) {
         bf16x8 af[2][MI], wf[2][NI];
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
@@ -212,6 +219,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][ni], af[kh][mi], acc[mi][ni], 0, 0, 0);
         }
     };
+    auto compute = [&](int stage_off) {
+#pragma unroll
+        for (int sub = 0; sub < KSUB; ++sub) compute_sub(stage_off + sub * SUB);
+    };
     if constexpr (STAGES == 2) {
         stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
         // Ring of STAGES K-tiles.  Iteration kt: wait for this wave's own pieces of K-tile kt (the younger K-tiles stay in
         // flight), barrier (RAW: every wave's pieces of kt have landed; WAR: every wave has finished reading kt - 1), request
         // K-tile kt + STAGES - 1 into the buffer kt - 1 lived in, compute kt.
-        constexpr int PER_STAGE = A_PER_WAVE + W_PER_WAVE;       // LDS-DMA instructions per wave and K-tile
+        constexpr int PER_STAGE = KSUB * (A_PER_WAVE + W_PER_WAVE);   // LDS-DMA instructions per wave and ring stage
         static_assert(STAGES <= 8 && PER_STAGE * (STAGES - 2) <= 63, "vmcnt is a 6-bit counter; the switch below has 7 cases");
 #pragma unroll
         for (int st = 0; st < STAGES - 1; ++st)
@@ -597,11 +608,13 @@ static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
     return HMM_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2>
+template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2, int KSUB = 1>
 static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                        hipStream_t st) {
-    constexpr int LDS = STAGES * (BM + BN) * 128;
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, STAGES>;
+    constexpr int LDS = STAGES * KSUB * (BM + BN) * 128;
+    static_assert(LDS <= 160 * 1024, "ring of the tiled GEMM: LDS");
+    HMM_REQUIRE((K / 64) % KSUB == 0, HMM_E_INVALID, "gemm: K = %d is not a multiple of %d (deep-K ring)", K, 64 * KSUB);
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, STAGES, KSUB>;
     HMM_ENSURE_DYN_LDS(kern, LDS);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
     kern<<<tiles_m * tiles_n, WM * WN * 64, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n);
@@ -619,6 +632,7 @@ HMM_TUNABLE(int, g_gemm_sliver_mt, 0)    // probe build: force 16 / 32 / 64 rows
 HMM_TUNABLE(int, g_gemm_sliver_auto, 1)  // probe build: 0 = the dispatcher never picks the sliver kernel
 HMM_TUNABLE(int, g_gemm_small_64, 512)   // launches of at most this many 64x64 tiles use them (behind the ring); 0 = never
 HMM_TUNABLE(int, g_gemm_small_32, 400)   // launches of at most this many 32x32 tiles use them (behind the ring); 0 = never
+HMM_TUNABLE(int, g_gemm_deepk, 1)        // probe build: 0 = never the deep-K rings (A/B)
 static bool ring32_fits(int M, int N) { return g_gemm_small_32 && (long)((M + 31) / 32) * (N / 32) <= g_gemm_small_32; }
 static float sliver_us(int M, int N, int K, int mt) {
     const long waves = (long)((M + 16 * mt - 1) / (16 * mt)) * (N / 16);
@@ -635,7 +649,12 @@ static int sliver_mt(int M, int N, int K) {
 static bool sliver_wins(int M, int N, int K, int epi) {
     if (!g_gemm_sliver_auto || epi > HMM_EPI_F32) return false;
     if ((long)((M + 63) / 64) * (N / 64) > 512) return false;               // that many rows: never
-    const float per_ktile = ring32_fits(M, N) ? 0.19f : 0.225f;               // what the launch would use instead
+    const long t32 = (long)((M + 31) / 32) * (N / 32);
+    float per_ktile = ring32_fits(M, N) ? 0.19f : 0.225f;                     // what the launch would use instead
+    if (g_gemm_deepk && ring32_fits(M, N)) {                                  // the deep-K rings (launch_gemm_small_epi)
+        if (K >= 2048 && (K >> 6) % 4 == 0 && t32 <= 256) per_ktile = 0.13f;
+        else if (K >= 1024 && (K >> 6) % 2 == 0 && t32 <= 192) per_ktile = 0.155f;
+    }
     return sliver_us(M, N, K, sliver_mt(M, N, K)) < 0.9f * (2.8f + per_ktile * (K >> 6));
 }
 
@@ -713,6 +732,22 @@ static int launch_gemm_ring32_epi(const bf16_t* A, const bf16_t* W, const float*
     return HMM_E_INVALID;
 }
 
+// Deep-K rings (KSUB K-tiles per stage): the epilogues of the plain rings
+template <int BM, int STAGES, int KSUB>
+static int launch_gemm_ringk_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                                 int epi, hipStream_t st) {
+#define HMM_CALL(E) launch_gemm<BM, BM, 2, 2, E, STAGES, KSUB>(A, W, bias, C, M, N, K, st)
+    switch (epi) {
+        case HMM_EPI_BIAS_BF16:      return HMM_CALL(HMM_EPI_BIAS_BF16);
+        case HMM_EPI_BIAS_GELU_BF16: return HMM_CALL(HMM_EPI_BIAS_GELU_BF16);
+        case HMM_EPI_BIAS_RESID_F32: return HMM_CALL(HMM_EPI_BIAS_RESID_F32);
+        case HMM_EPI_F32:            return HMM_CALL(HMM_EPI_F32);
+    }
+#undef HMM_CALL
+    set_error("gemm: deep-K tiles have no epilogue %d", epi);
+    return HMM_E_INVALID;
+}
+
 static int launch_gemm_ring128_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                                    int epi, hipStream_t st) {
 #define HMM_CALL(E) launch_gemm<128, 128, 2, 2, E, 4>(A, W, bias, C, M, N, K, st)
@@ -737,7 +772,14 @@ static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* 
                                  int epi, hipStream_t st, bool tail = false) {
     if (g_gemm_small_stages == 2 || (long)((M + 127) / 128) * (N / 128) > 256)
         return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
-    if (!tail && epi <= HMM_EPI_F32 && ring32_fits(M, N)) return launch_gemm_ring32_epi(A, W, bias, C, M, N, K, epi, st);
+    if (!tail && epi <= HMM_EPI_F32 && ring32_fits(M, N)) {
+        // deep-K rings while the launch leaves most CUs a workgroup of their own (tools/deepk_probe.py, cold weights): one
+        // question's fc2 (96 tiles, K = 4096) 16.4 -> 10.5 us with four K-tiles per stage, its out-proj 6.3 -> 5.3 with two
+        const long t32 = (long)((M + 31) / 32) * (N / 32);
+        if (g_gemm_deepk && K >= 2048 && (K >> 6) % 4 == 0 && t32 <= 256) return launch_gemm_ringk_epi<32, 4, 4>(A, W, bias, C, M, N, K, epi, st);
+        if (g_gemm_deepk && K >= 1024 && (K >> 6) % 2 == 0 && t32 <= 192) return launch_gemm_ringk_epi<32, 4, 2>(A, W, bias, C, M, N, K, epi, st);
+        return launch_gemm_ring32_epi(A, W, bias, C, M, N, K, epi, st);
+    }
     if (g_gemm_small_64 &&
         (long)((M + 63) / 64) * (N / 64) <= (tail ? g_gemm_tail_64 : g_gemm_small_64))
         return launch_gemm_ring64_epi(A, W, bias, C, M, N, K, epi, st);
@@ -798,6 +840,8 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         case HMM_GEMM_TILE_128x128_RING: return launch_gemm_ring128_epi(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_64x64_RING:   return launch_gemm_ring64_epi(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_32x32_RING:   return launch_gemm_ring32_epi(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_32x32_RING_K2: return launch_gemm_ringk_epi<32, 4, 2>(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_32x32_RING_K4: return launch_gemm_ringk_epi<32, 4, 4>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_256x256_PP: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_128x128:    return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_256x128:    return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);

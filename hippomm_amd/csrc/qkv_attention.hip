@@ -49,12 +49,26 @@ struct FusedPlan {
     static_assert(G::T + (G::BIAS_KV ? 1 : 0) <= Cfg::NKEY && G::T - G::ROW0 <= 256 && 3 * G::DH <= 256, "tile geometry");
 };
 
+#ifdef HMM_PROBE
+// in-kernel stamps per workgroup (16 slots): 0 start, 1 projection loop done, 2 Q/K/V images written, 3 main query tiles done,
+// 4 end (stores retired); 6 / 7 / 8 shader-clock ticks at 0 / 1 / 4; 9 XCC id
+unsigned long long* g_fused_stamps = nullptr;
+extern "C" void hmm_probe_set_fused_stamps(unsigned long long* p) { g_fused_stamps = p; }
+#define HMM_FUSED_PROBE_ARG , unsigned long long* stamps
+#define HMM_FUSED_PROBE_VAL , g_fused_stamps
+#define HMM_FSTAMP(slot, expr) if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (slot)] = (expr);
+#else
+#define HMM_FUSED_PROBE_ARG
+#define HMM_FUSED_PROBE_VAL
+#define HMM_FSTAMP(slot, expr)
+#endif
+
 template <class G>
 __global__ __launch_bounds__(512) void qkv_attention_kernel(
     const bf16_t* __restrict__ a /* [n_img*T][D] LayerNorm output */, const bf16_t* __restrict__ w /* [3D][D] */,
     const float* __restrict__ bias /* [3D] */, const bf16_t* __restrict__ qkv_cls /* [n_img][3D], CLS_OUTSIDE only */,
     bf16_t* __restrict__ out /* [n_img*T][D] */, int n_img, float scale_log2e,
-    const float* __restrict__ bias_k /* [D], BIAS_KV only */, const float* __restrict__ bias_v) {
+    const float* __restrict__ bias_k /* [D], BIAS_KV only */, const float* __restrict__ bias_v HMM_FUSED_PROBE_ARG) {
     using P = FusedPlan<G>;
     using Cfg = typename P::Cfg;
     constexpr int kD = G::D, kH = G::H, kDH = G::DH, kT = G::T;
@@ -67,6 +81,9 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
     const int h = n % kH;
     if (b_lin >= n_img) return;
     const int b = n_img - 1 - b_lin;
+    HMM_FSTAMP(0, __builtin_amdgcn_s_memrealtime())
+    HMM_FSTAMP(6, __builtin_amdgcn_s_memtime())
+    HMM_FSTAMP(9, __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)))
 
     // ---- 1. projection tile: rows = the sample's tokens ROW0 .. ROW0+255, columns = [q_h | k_h | v_h | unused] ----------
     PPSources src;
@@ -95,6 +112,8 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     pp_mainloop<G::TAIL>(a, w, src, kD >> 6, smem, lane, wave, acc);   // the unused columns: no MFMAs
+    HMM_FSTAMP(1, __builtin_amdgcn_s_memrealtime())
+    HMM_FSTAMP(7, __builtin_amdgcn_s_memtime())
 
     // ---- 2. accumulators -> Q / K / V images (the staging buffers are dead: see pp_mainloop) --------------------------
     char* k_lds = smem;
@@ -146,6 +165,7 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
         }
     }
     __syncthreads();
+    HMM_FSTAMP(2, __builtin_amdgcn_s_memrealtime())
 
     // ---- 3. attention on the images ------------------------------------------------------------------------------------
     const int r = lane & 31, hh = lane >> 5;
@@ -160,7 +180,16 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
         for (int ks = 0; ks < Cfg::KS; ++ks) qf[ks] = load_q(qr, ks);
     }
     attention_core<kDH, G::NKT>(k_lds, v_lds, reinterpret_cast<float*>(smem + P::XOff), load_q, qf,
-                                out + (size_t)b * kT * kD + h * kDH, kT, kT + (G::BIAS_KV ? 1 : 0), kD, scale_log2e, false);
+                                out + (size_t)b * kT * kD + h * kDH, kT, kT + (G::BIAS_KV ? 1 : 0), kD, scale_log2e, false
+#ifdef HMM_PROBE
+                                , stamps ? stamps + (size_t)blockIdx.x * 16 : nullptr
+#endif
+                                );
+#ifdef HMM_PROBE
+    if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+#endif
+    HMM_FSTAMP(4, __builtin_amdgcn_s_memrealtime())
+    HMM_FSTAMP(8, __builtin_amdgcn_s_memtime())
 }
 
 template <class G>
@@ -171,7 +200,7 @@ static int launch_fused(const bf16_t* a, const bf16_t* w, const float* bias, con
     const int grid = 8 * ((n_img + 7) / 8) * G::H;
     auto kern = qkv_attention_kernel<G>;
     HMM_ENSURE_DYN_LDS(kern, FusedPlan<G>::Lds);
-    kern<<<grid, 512, FusedPlan<G>::Lds, st>>>(a, w, bias, qkv_cls, out, n_img, scale_log2e, bias_k, bias_v);
+    kern<<<grid, 512, FusedPlan<G>::Lds, st>>>(a, w, bias, qkv_cls, out, n_img, scale_log2e, bias_k, bias_v HMM_FUSED_PROBE_VAL);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }

@@ -70,6 +70,40 @@ class FeatureStore:
                    "hmm_cosine_topk")
         return idx, sims
 
+    def build_shadow(self):
+        """Build the bf16 shadow of the store (2048 B per row beside the 4096-B fp32 rows; hmm_shadow_store_build) that
+        ``search_prefiltered_device`` streams.  Idempotent."""
+        if getattr(self, "_shadow", None) is None:
+            lib = _lib.load()
+            n = len(self)
+            self._shadow = torch.empty(lib.hmm_shadow_store_bytes(n), dtype=torch.uint8, device=self.rows.device)
+            _lib.check(lib.hmm_shadow_store_build(self.rows.data_ptr(), n, FEATURE_DIM, self._shadow.data_ptr(),
+                                                  self._shadow.numel(), _lib.stream_ptr()), "hmm_shadow_store_build")
+        return self
+
+    def search_prefiltered_device(self, query: torch.Tensor, k: int, stats: torch.Tensor = None):
+        """``search_device`` through the bf16 shadow: candidates from one pass over 2048 B per row, re-scored exactly on the
+        fp32 rows -- the same (idx, sims) as ``search_device``, bit for bit (hmm_cosine_topk_prefilter).  ``stats``: optional
+        int32[2] CUDA tensor receiving (candidates re-scored, saturated lists)."""
+        lib = _lib.load()
+        self.build_shadow()
+        n = len(self)
+        if k < 1:
+            raise ValueError("k must be >= 1")
+        k_out = min(k, n)
+        need = lib.hmm_cosine_topk_prefilter_workspace_bytes(n, k)
+        if getattr(self, "_ws_pre", None) is None or self._ws_pre.numel() < need:
+            self._ws_pre = torch.empty(need, dtype=torch.uint8, device=self.rows.device)
+        idx = torch.empty(k_out, dtype=torch.int64, device=self.rows.device)
+        sims = torch.empty(k_out, dtype=torch.float32, device=self.rows.device)
+        n_out = torch.empty(1, dtype=torch.int32, device=self.rows.device)
+        _lib.check(lib.hmm_cosine_topk_prefilter(self.rows.data_ptr(), self._shadow.data_ptr(), n, FEATURE_DIM, query.data_ptr(), k,
+                                                 idx.data_ptr(), sims.data_ptr(), n_out.data_ptr(),
+                                                 stats.data_ptr() if stats is not None else None,
+                                                 self._ws_pre.data_ptr(), self._ws_pre.numel(), _lib.stream_ptr()),
+                   "hmm_cosine_topk_prefilter")
+        return idx, sims
+
     def search_keys_device(self, query: torch.Tensor, k: int) -> torch.Tensor:
         """Local top-k as packed order keys (uint64 bit patterns in an int64 tensor, 0-padded to k)
         for the sharded scan (hippomm_amd.sharding.sharded_top_k)."""

@@ -83,6 +83,24 @@ int    hmm_topk_merge_keys(const uint64_t* keys_dev /* [n_shards][k] */, int n_s
                            int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
                            hmm_stream_t stream);
 
+/* feature_search through a bf16 SHADOW of the store (SURVEY 8d's optional shadow store; reported separately against
+ * 2048 B per row).  hmm_shadow_store_build writes shadow row r = bf16(store[r] / ||store[r]||) (2048 B per row, NaN for a
+ * zero-norm or non-finite row); hmm_cosine_topk_prefilter streams the shadow for approximate similarities, keeps every row that
+ * can be among the k best under a proven error bound (|s~ - s| < 0.004: bf16 has an 8-bit significand), re-scores those rows on
+ * the fp32 store with the arithmetic of hmm_cosine_topk and returns the k best: the SAME indices and the SAME fp32 similarities,
+ * bit for bit, as hmm_cosine_topk (vector_ops.py:178-186 semantics, same total order).  When the candidate set is not provably
+ * complete (a store of thousands of near-ties) the exact scan runs instead, inside the same call, decided on the device.
+ * k > 64 or fewer than 16384 rows: the call IS hmm_cosine_topk.  stats_out_dev (may be null) int32[2]: candidates re-scored and
+ * saturated block lists of the last call (-1, -1 when the prefilter was not used); a non-zero second entry or more than 1024
+ * candidates means the exact scan answered. */
+size_t hmm_shadow_store_bytes(int64_t n_rows);
+int    hmm_shadow_store_build(const float* store_dev, int64_t n_rows, int dim, void* shadow_dev, size_t shadow_bytes,
+                              hmm_stream_t stream);
+size_t hmm_cosine_topk_prefilter_workspace_bytes(int64_t n_rows, int k);
+int    hmm_cosine_topk_prefilter(const float* store_dev, const void* shadow_dev, int64_t n_rows, int dim,
+                                 const float* query_dev, int k, int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
+                                 int32_t* stats_out_dev, void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
+
 /* Batched feature_search: the top-k of n_queries queries against the same store in ONE pass over it
  * (16 queries per pass; the Q x rows similarity block runs on the fp32 matrix cores, so a row is still read once from
  * HBM).  The reference calls top_k_cosine_similarity once per question (hippomm/utils/vector_ops.py:151-188 via
@@ -236,6 +254,8 @@ int hmm_op_gemm_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* 
 #define HMM_GEMM_TILE_128x128_RING 6 /* 128x128 tiles behind a 4-deep LDS-DMA ring (counted vmcnt): launches of few tiles, peeled tails */
 #define HMM_GEMM_TILE_64x64_RING  7  /* 64x64 tiles, 4 waves, behind the same ring: more workgroups for mid-size M with a long K */
 #define HMM_GEMM_TILE_32x32_RING  8  /* 32x32 tiles, one 16x16 block per wave, same ring: a few dozen rows x a long K */
+#define HMM_GEMM_TILE_32x32_RING_K2 9   /* 32x32 tiles, deep K: 2 K-tiles per ring stage, 4 stages (64 KiB: two workgroups per CU); K % 128 == 0 */
+#define HMM_GEMM_TILE_32x32_RING_K4 10  /* 32x32 tiles, 4 K-tiles per stage, 4 stages (128 KiB): few rows x a long K (one question's fc2); K % 256 == 0 */
 int hmm_op_gemm_bf16_tile(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
                           void* c_dev, int M, int N, int K, int epilogue, int tile, hmm_stream_t stream);
 /* y_bf16[rows, D] = LayerNorm(x_f32[rows, D]) * gamma + beta ; D in {768, 1280} */

@@ -1,0 +1,153 @@
+"""GPU parity of the bf16-prefilter scan (hmm_cosine_topk_prefilter, SURVEY 8d's optional shadow store): it must return what
+hmm_cosine_topk returns -- the same rows and the same fp32 similarities BIT FOR BIT -- on random stores, on stores where the
+bf16 rounding error is larger than the gaps between ranks (clusters of near-duplicate rows, as consecutive video frames are),
+on ties, NaN rows and a zero query, at sizes on both sides of its dispatch limits, on the reference's golden vectors, and at the
+BASELINE size.  The reference function is hippomm/utils/vector_ops.py:151-188."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import recipes
+from test_gpu_scan import GOLD, SIM_ATOL, _sims, assert_topk_matches
+
+pytestmark = pytest.mark.gpu
+
+
+def both(store, q, k):
+    """(exact idx, exact sims, prefiltered idx, prefiltered sims, stats) as numpy."""
+    from hippomm_amd.vector_ops import FeatureStore
+    fs = FeatureStore(store)
+    qd = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).cuda()
+    stats = torch.full((2,), -7, dtype=torch.int32, device="cuda")
+    i0, s0 = fs.search_device(qd, k)
+    i1, s1 = fs.search_prefiltered_device(qd, k, stats)
+    return i0.cpu().numpy(), s0.cpu().numpy(), i1.cpu().numpy(), s1.cpu().numpy(), stats.cpu().tolist()
+
+
+def assert_identical(i0, s0, i1, s1):
+    assert i1.dtype == np.int64 and i0.tolist() == i1.tolist()
+    assert s0.view(np.int32).tolist() == s1.view(np.int32).tolist()      # the same bits, NaN included
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (63, 5), (4097, 32), (16383, 32), (16384, 32), (16385, 1), (20000, 5), (20000, 64),
+                                 (20000, 65), (70001, 32), (300001, 64), (300001, 100)])
+def test_equals_the_exact_scan_on_random_stores(n, k):
+    rng = np.random.default_rng(n * 17 + k)
+    store = rng.standard_normal((n, 1024), dtype=np.float32)
+    q = rng.standard_normal(1024, dtype=np.float32)
+    i0, s0, i1, s1, stats = both(store, q, k)
+    assert_identical(i0, s0, i1, s1)
+    assert_topk_matches(i1, s1, store, q, k)
+    if n >= 16384 and k <= 64:
+        assert stats[1] == 0 and k <= stats[0] <= 4 * k + 64, stats        # the prefilter answered, with few extra candidates
+    else:
+        assert stats == [-1, -1]                                             # below the dispatch limits the call IS the exact scan
+
+
+def test_clusters_of_near_duplicates_where_bf16_error_exceeds_the_rank_gaps():
+    """Scenes of 40 near-identical frames: inside a scene the similarities to a query differ by ~1e-5 while the shadow's error is
+    ~1e-3, so the approximate ranking inside the winning scenes is wrong and only the margin + exact re-score can be right."""
+    rng = np.random.default_rng(5)
+    scenes = rng.standard_normal((600, 1024), dtype=np.float32)
+    store = np.repeat(scenes, 40, axis=0) + 2e-3 * rng.standard_normal((24000, 1024), dtype=np.float32)
+    q = scenes[123] + 0.5 * scenes[77] + 0.05 * rng.standard_normal(1024, dtype=np.float32)
+    for k in (5, 32, 64):
+        i0, s0, i1, s1, stats = both(store, q, k)
+        assert_identical(i0, s0, i1, s1)
+        assert stats[0] >= 40 or stats[1] > 0, stats                         # the whole winning scene had to be re-scored
+    # the approximate order really is wrong here: the bf16 similarities of the winning scene rank differently
+    shadow = torch.from_numpy(store[123 * 40:124 * 40]).cuda()
+    shadow = (shadow / shadow.norm(dim=1, keepdim=True)).to(torch.bfloat16).float()
+    approx = (shadow @ torch.from_numpy(q).cuda()).cpu().numpy()
+    exact = (store[123 * 40:124 * 40].astype(np.float64) @ q.astype(np.float64)) / np.linalg.norm(store[123 * 40:124 * 40].astype(np.float64), axis=1)
+    assert np.argsort(-approx).tolist() != np.argsort(-exact).tolist()
+
+
+def test_query_aligned_with_the_rounding_error_of_the_best_row():
+    """The query leans against the bf16 rounding error of its own best match, so that row's approximate similarity is pushed
+    down by ~1e-3 -- below decoys whose true similarity is lower.  The exact answer must still come back."""
+    rng = np.random.default_rng(9)
+    store = rng.standard_normal((30000, 1024), dtype=np.float32)
+    v = store[4321] / np.linalg.norm(store[4321])
+    vt = torch.from_numpy(v).to(torch.bfloat16).float().numpy()
+    e = vt - v
+    q = (v - 0.6 * e / np.linalg.norm(e)).astype(np.float32)
+    for j in range(64):                                                       # decoys: a little further from v than v itself
+        store[100 + 7 * j] = v + (0.02 + 0.0005 * j) * rng.standard_normal(1024).astype(np.float32) / 32
+    i0, s0, i1, s1, stats = both(store, q, 32)
+    assert_identical(i0, s0, i1, s1)
+    assert 4321 in i1.tolist()
+
+
+def test_many_exact_ties_and_nan_rows_take_the_fallback_and_stay_identical():
+    rng = np.random.default_rng(11)
+    base = rng.standard_normal((16, 1024), dtype=np.float32)
+    store = base[rng.integers(0, 16, size=40000)]                             # every row ~2500 times
+    store[[17, 4000, 39999]] = 0.0                                            # NaN rows rank first
+    q = rng.standard_normal(1024, dtype=np.float32)
+    for k in (3, 32):
+        i0, s0, i1, s1, stats = both(store, q, k)
+        assert_identical(i0, s0, i1, s1)
+        assert i1[:3].tolist() == [39999, 4000, 17] and np.isnan(s1[:3]).all()
+    assert stats[1] > 0 or stats[0] > 1024, stats                             # 2500 equal best rows: more candidates than pass 2 re-scores, the exact scan answered
+
+
+def test_zero_and_nan_queries():
+    store = np.random.default_rng(1).standard_normal((20000, 1024), dtype=np.float32)
+    for q in (np.zeros(1024, np.float32), np.full(1024, np.nan, np.float32)):
+        i0, s0, i1, s1, _ = both(store, q, 4)
+        assert_identical(i0, s0, i1, s1)
+        assert i1.tolist() == [19999, 19998, 19997, 19996] and np.isnan(s1).all()
+
+
+def test_text_query_shaped_case():
+    """A cross-modal query: norm 1 / 0.07, similarities 0.04 - 0.4 against unit rows (the gaps of a real text -> vision query)."""
+    rng = np.random.default_rng(21)
+    rows = rng.standard_normal((50000, 1024), dtype=np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    q = (rows[777] * 0.3 + rng.standard_normal(1024).astype(np.float32) / 32)
+    q = (q / np.linalg.norm(q) / 0.07).astype(np.float32)
+    i0, s0, i1, s1, stats = both(rows, q, 5)
+    assert_identical(i0, s0, i1, s1)
+    assert i1[0] == 777 and stats[1] == 0
+
+
+@pytest.mark.parametrize("name", recipes.SCAN_CASES)
+def test_golden_vectors_through_the_prefilter_entry_point(name):
+    from hippomm_amd.vector_ops import FeatureStore
+    case = GOLD[name]
+    q, store, k = recipes.scan_case(name)
+    if k < 1 or len(np.atleast_2d(store)) == 0:
+        pytest.skip("k <= 0 / empty store are host-side conventions of top_k_cosine_similarity")
+    fs = FeatureStore(store)
+    qd = torch.from_numpy(np.ascontiguousarray(np.asarray(q).reshape(-1), dtype=np.float32)).cuda()
+    idx, sims = fs.search_prefiltered_device(qd, k)
+    assert idx.cpu().tolist() == case["indices"]
+    np.testing.assert_allclose(sims.cpu().numpy(), _sims(case), rtol=0, atol=SIM_ATOL, equal_nan=True)
+
+
+def test_full_size_1m_rows_identical_to_the_exact_scan():
+    from hippomm_amd.vector_ops import FeatureStore
+    n, k = 1_000_000, 32
+    g = torch.Generator(device="cuda").manual_seed(42)
+    rows = torch.empty(n, 1024, dtype=torch.float32, device="cuda")
+    for s in range(0, n, 125_000):
+        blk = torch.randn(125_000, 1024, generator=g, device="cuda")
+        rows[s:s + 125_000] = blk / blk.norm(dim=1, keepdim=True)
+    fs = FeatureStore(rows).build_shadow()
+    stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for seed in (43, 44, 45):
+        q = torch.randn(1024, generator=torch.Generator(device="cuda").manual_seed(seed), device="cuda")
+        i0, s0 = fs.search_device(q, k)
+        i1, s1 = fs.search_prefiltered_device(q, k, stats)
+        assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+        st = stats.cpu().tolist()
+        assert st[1] == 0 and k <= st[0] <= 200, st
+    # the shadow is what the header says: bf16(row / ||row||), row-major
+    sh = fs._shadow.view(torch.bfloat16).view(n, 1024)
+    pick = torch.tensor([0, 1, 499_999, 999_999], device="cuda")
+    want = (rows[pick] / rows[pick].norm(dim=1, keepdim=True)).to(torch.bfloat16)
+    assert (sh[pick].float() - want.float()).abs().max().item() <= 2 ** -8 * want.float().abs().max().item()

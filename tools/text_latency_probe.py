@@ -14,6 +14,7 @@ set_auto = setter(lib, "g_gemm_sliver_auto")
 set_stages = setter(lib, "g_gemm_small_stages")
 set_64 = setter(lib, "g_gemm_small_64")
 set_32 = setter(lib, "g_gemm_small_32")
+set_deepk = setter(lib, "g_gemm_deepk")
 from hippomm_amd.encoder import HipTower, synthetic_state_dict   # noqa: E402
 
 rows = []
@@ -55,8 +56,10 @@ for kind, batches in (("text", (1, 2, 3, 4, 8, 16, 64)), ("vision", (1, 2, 4, 8,
             x = torch.randn(B, 3, 224, 224, device="cuda")
         rec = {"tower": kind, "batch": B}
         outs = []
-        for tag, auto, stages, t64, t32 in (("tiled", 0, 2, 0, 0), ("ring128", 0, 4, 0, 0), ("ring64", 0, 4, 512, 0),
-                                            ("ring64_sliver", 1, 4, 512, 0), ("product", 1, 4, 512, 400)):
+        for tag, auto, stages, t64, t32, dk in (("tiled", 0, 2, 0, 0, 0), ("ring128", 0, 4, 0, 0, 0), ("ring64", 0, 4, 512, 0, 0),
+                                                ("ring64_sliver", 1, 4, 512, 0, 0), ("round3_product", 1, 4, 512, 400, 0),
+                                                ("product", 1, 4, 512, 400, 1)):
+            set_deepk(dk)
             set_auto(auto)
             set_stages(stages)
             set_64(t64)
