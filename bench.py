@@ -364,6 +364,7 @@ def scan_bench(do_cpu):
     i_ex, s_ex = store.search_device(q, SCAN_K)
     i_pre, s_pre = store.search_prefiltered_device(q, SCAN_K, stats)
     shadow_bytes = SCAN_ROWS * 2048.0
+    pre_traffic, pre_src = profile_summary("r*_prefilter_pmc_summary.json", "prefilter_topk_kernel")
     out["prefilter_bf16_shadow"] = {
         "what": "hmm_cosine_topk_prefilter: bf16 shadow (row / ||row||, 2048 B per row) streamed for candidates under a proven "
                 "error bound, exact fp32 re-score of the candidates; same result as the fp32 scan",
@@ -372,7 +373,7 @@ def scan_bench(do_cpu):
         "candidates_rescored": int(stats[0].item()), "saturated_lists": int(stats[1].item()),
         "roofline": {"bound": "hbm", "kernel": "prefilter_topk_kernel (+ prefilter_final_kernel)", "scope": "whole query",
                      "achieved": round(shadow_bytes / ms_pre / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": round(shadow_bytes / ms_pre / 1e6 / PEAK_HBM_GBS, 4), "traffic": None,
+                     "frac": round(shadow_bytes / ms_pre / 1e6 / PEAK_HBM_GBS, 4), "traffic": pre_traffic, "traffic_source": pre_src,
                      "bytes_per_launch": shadow_bytes, "ms_per_launch": round(ms_pre, 4)},
         "extra_hbm_bytes_held": shadow_bytes}
     # batched questions: 16 queries per pass over the same store
@@ -459,10 +460,15 @@ def retrieval_bench(rows, do_cpu):
     t_tower = event_time_ms(lambda: tower.forward_into(tok([question]).cuda(), emb), 10, warmup=2)
     q = emb[0].clone()
     t_scan = event_time_ms(lambda: events.search_segments_device(q, events.offsets, 5), 10, warmup=2)
+    events.build_shadow()
+    t_scan_pre = event_time_ms(lambda: events.search_segments_device(q, events.offsets, 5, prefilter=True), 10, warmup=2)
+    ex, pre = events.search_segments_device(q, events.offsets, 5), events.search_segments_device(q, events.offsets, 5, prefilter=True)
+    pre_same = bool(torch.equal(ex[0], pre[0]) and torch.equal(ex[1].view(torch.int32), pre[1].view(torch.int32)) and torch.equal(ex[2], pre[2]))
     out = {"what": "question -> tokenizer -> text tower (24 blocks, batch 1) -> top-5 per event over 2000 events x 500 rows "
                    "(one pass) -> best 5 hits on the host",
            "ms_end_to_end": round(sorted(t)[len(t) // 2] * 1e3, 3), "ms_text_tower": round(t_tower, 3),
            "ms_per_event_scan_all_events": round(t_scan, 3), "events": n_events, "rows": n_events * per_event,
+           "ms_per_event_scan_bf16_prefilter": round(t_scan_pre, 3), "prefilter_identical_to_fp32_scan": pre_same,
            "ms_end_to_end_ranked_on_device": round(sorted(t2)[len(t2) // 2] * 1e3, 3),
            "device_ranking_equals_host_ranking": [(e, i) for e, i, _ in top2] == [(e, i) for _, e, i in top]}
     if do_cpu:
@@ -932,6 +938,8 @@ def main():
         rp = line.get("scan", {}).get("retrieval", {}).get("parity_vs_oracle")
         if rp and not (rp["top5_of_first_200_events_equal"] and 1 - rp["text_embedding_cos"] <= 5e-5):
             bad.append("scan.retrieval.parity_vs_oracle")
+        if not line.get("scan", {}).get("retrieval", {}).get("prefilter_identical_to_fp32_scan", True):
+            bad.append("scan.retrieval.prefilter")
         for tag in ("weak_1M_rows_per_gpu", "strong_1M_rows_total"):
             if "scan" in line and not line["scan"].get(tag, {}).get("indices_match_torch_where_separated", True):
                 bad.append(f"scan.{tag}")

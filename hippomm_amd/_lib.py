@@ -30,6 +30,9 @@ _SIGNATURES = {
     "hmm_cosine_topk_prefilter_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "hmm_cosine_topk_prefilter": (C.c_int, [c_ptr, c_ptr, C.c_int64, C.c_int, c_ptr, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr,
                                             c_ptr, C.c_size_t, c_ptr]),
+    "hmm_cosine_topk_segmented_prefilter_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "hmm_cosine_topk_segmented_prefilter": (C.c_int, [c_ptr, c_ptr, C.c_int64, C.c_int, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, c_ptr,
+                                                      c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "hmm_cosine_topk_segmented_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "hmm_cosine_topk_segmented": (C.c_int, [c_ptr, C.c_int64, C.c_int, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr,
                                             c_ptr, C.c_size_t, c_ptr]),

@@ -251,6 +251,141 @@ static int prefilter_list_len(int k) {
     return kk > kPrefilterMaxK ? kPrefilterMaxK : kk;
 }
 
+// ---- per-event variant (hmm_cosine_topk_segmented through the shadow) -------------------------------------------------------
+// pass 1: s~ of every row, written as whole 128-B lines (a wave takes 32 consecutive rows, four at a time)
+__global__ __launch_bounds__(256) void prefilter_sims_kernel(const uint4* __restrict__ shadow, int64_t n_rows,
+                                                             const float4* __restrict__ query, float* __restrict__ sims) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    float4 q[4];
+    float qs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 t = query[j * 64 + lane];
+        qs = fmaf(t.x, t.x, qs); qs = fmaf(t.y, t.y, qs); qs = fmaf(t.z, t.z, qs); qs = fmaf(t.w, t.w, qs);
+    }
+    q[0] = query[2 * lane]; q[1] = query[2 * lane + 1]; q[2] = query[128 + 2 * lane]; q[3] = query[128 + 2 * lane + 1];
+    const float inv_qlen = 1.0f / sqrtf(wave_sum(qs));
+    for (int64_t base = wave * 32; base < n_rows; base += n_waves * 32) {
+        float mine = 0.f;                                         // lane l < 32: s~ of row base + l
+        const int64_t left = n_rows - base;
+        const int steps = left >= 32 ? 8 : (int)((left + 3) >> 2);           // wave-uniform
+        for (int j = 0; j < steps; ++j) {
+            const int64_t r = base + 4 * j;
+            uint4 x[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4* p = shadow + (r + i < n_rows ? r + i : r) * 128 + lane;
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+                const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 64));
+                x[i][0] = make_uint4(a[0], a[1], a[2], a[3]);
+                x[i][1] = make_uint4(b[0], b[1], b[2], b[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = wave_sum(dot8_bf16(x[i][1], q[2], q[3], dot8_bf16(x[i][0], q[0], q[1], 0.f))) * inv_qlen;
+                mine = lane == 4 * j + i ? d : mine;
+            }
+        }
+        if (lane < 32 && base + lane < n_rows) sims[base + lane] = mine;
+    }
+}
+
+// pass 2: one workgroup per event.  The event's k-th largest s~ gives the threshold, the rows at or above it are re-scored on the
+// fp32 store (exact_row_sim) and the k best of those are the event's answer -- what segment_topk_kernel returns on the exact
+// similarities.  More candidates than the buffer holds (an event of near-identical rows): every row of the event is re-scored.
+constexpr int kSegCandCap = 1024;
+__global__ __launch_bounds__(1024) void segment_prefilter_kernel(const float* __restrict__ sims, const int64_t* __restrict__ seg_off,
+                                                                 int k, const float4* __restrict__ store,
+                                                                 const float4* __restrict__ query, int64_t* __restrict__ idx_out,
+                                                                 float* __restrict__ sim_out, int32_t* __restrict__ n_out) {
+    __shared__ uint64_t s[kChunk];
+    __shared__ uint32_t cand[kSegCandCap];
+    __shared__ int n_cand;
+    const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t lo = seg_off[e], hi = seg_off[e + 1];
+    const int64_t n = hi - lo;
+    const int k_out = (int)(n < k ? (n > 0 ? n : 0) : k);
+    if (tid == 0) n_cand = 0;
+    if (n <= 0) {                                                  // block-uniform
+        if (tid == 0) n_out[e] = 0;
+        for (int t = tid; t < k; t += 1024) { idx_out[(int64_t)e * k + t] = -1; sim_out[(int64_t)e * k + t] = 0.0f; }
+        return;
+    }
+    // ---- the k-th largest approximate key of the event (pieces of a chunk, carrying the running best k) ---------------------
+    uint32_t thr = 0u;                                             // n <= k: every row is a candidate
+    if (n > k) {
+        int have = 0;
+        int64_t base = 0;
+        do {
+            const int64_t left = n - base;
+            const int take = (int)(left < (int64_t)(kChunk - have) ? left : (int64_t)(kChunk - have));
+            const int total = have + take;
+            const int n2 = pow2_at_least(total, 64);
+            for (int t = have + tid; t < n2; t += 1024) {
+                uint64_t key = 0ull;
+                if (t < total) {
+                    const int64_t r = base + (t - have);
+                    key = ((uint64_t)order_bits(sims[lo + r]) << 32) | (uint64_t)(uint32_t)r;
+                }
+                s[t] = key;
+            }
+            __syncthreads();
+            top64_desc(s, n2);
+            have = total < k ? total : k;
+            base += take;
+        } while (base < n);
+        const float t_lo = order_bits_inverse((uint32_t)(s[k - 1] >> 32)) - 2.0f * kPrefilterEps;
+        thr = order_bits(t_lo);
+    }
+    __syncthreads();
+    // ---- candidates ---------------------------------------------------------------------------------------------------------
+    for (int64_t r = tid; r < n; r += 1024) {
+        if (order_bits(sims[lo + r]) >= thr) {
+            const int pos = atomicAdd(&n_cand, 1);
+            if (pos < kSegCandCap) cand[pos] = (uint32_t)r;
+        }
+    }
+    __syncthreads();
+    const bool all_rows = n_cand > kSegCandCap;                    // block-uniform
+    const int64_t m = all_rows ? n : (int64_t)n_cand;
+    // ---- exact re-score, k best (pieces of a chunk with carry, as above) ------------------------------------------------------
+    float4 q[4];
+    float qs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        q[j] = query[j * 64 + lane];
+        qs = fmaf(q[j].x, q[j].x, qs); qs = fmaf(q[j].y, q[j].y, qs);
+        qs = fmaf(q[j].z, q[j].z, qs); qs = fmaf(q[j].w, q[j].w, qs);
+    }
+    const float q_len = sqrtf(wave_sum(qs));
+    int have = 0;
+    int64_t base = 0;
+    do {
+        const int64_t left = m - base;
+        const int take = (int)(left < (int64_t)(kChunk - have) ? left : (int64_t)(kChunk - have));
+        const int total = have + take;
+        const int n2 = pow2_at_least(total, 64);
+        for (int t = total + tid; t < n2; t += 1024) s[t] = 0ull;
+        for (int c = wave; c < take; c += 16) {                    // wave-uniform trip count per wave
+            const int64_t r = all_rows ? base + c : (int64_t)cand[base + c];
+            const float sim = exact_row_sim(store + (lo + r) * 256 + lane, q, q_len);
+            if (lane == 0) s[have + c] = ((uint64_t)order_bits(sim) << 32) | (uint64_t)(uint32_t)r;
+        }
+        __syncthreads();
+        top64_desc(s, n2);
+        have = total < k ? total : k;
+        base += take;
+    } while (base < m);
+    if (tid == 0) n_out[e] = k_out;
+    for (int t = tid; t < k; t += 1024) {
+        const bool ok = t < k_out;
+        idx_out[(int64_t)e * k + t] = ok ? (int64_t)(s[t] & 0xFFFFFFFFull) : -1;
+        sim_out[(int64_t)e * k + t] = ok ? order_bits_inverse((uint32_t)(s[t] >> 32)) : 0.0f;
+    }
+}
+
 struct PrefilterPlan { size_t off_exact, off_lists, off_flag, total; int blocks; };
 
 static PrefilterPlan prefilter_plan(int64_t n, int k) {
@@ -328,4 +463,35 @@ extern "C" int hmm_cosine_topk_prefilter(const float* store_dev, const void* sha
     HMM_LAUNCH_CHECK();
     // the exact scan, executed only when the flag is up (both kernels return at once otherwise)
     return cosine_topk_if(flag, store_dev, n_rows, query_dev, k, idx_out_dev, sim_out_dev, n_out_dev, ws + p.off_exact, p.off_lists, st);
+}
+
+extern "C" size_t hmm_cosine_topk_segmented_prefilter_workspace_bytes(int64_t n_rows, int n_segments, int k) {
+    return hmm_cosine_topk_segmented_workspace_bytes(n_rows, n_segments, k);
+}
+
+extern "C" int hmm_cosine_topk_segmented_prefilter(const float* store_dev, const void* shadow_dev, int64_t n_rows, int dim,
+                                                   const float* query_dev, const int64_t* seg_offsets_dev, int n_segments, int k,
+                                                   int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
+                                                   void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream) {
+    if (k > kPrefilterMaxK || n_rows == 0)                                  // no tournament beyond 64 keys: the exact path
+        return hmm_cosine_topk_segmented(store_dev, n_rows, dim, query_dev, seg_offsets_dev, n_segments, k, idx_out_dev, sim_out_dev,
+                                         n_out_dev, workspace_dev, workspace_bytes, stream);
+    HMM_REQUIRE(dim == HMM_FEATURE_DIM, HMM_E_INVALID, "cosine_topk_segmented_prefilter: dim must be %d, got %d", HMM_FEATURE_DIM, dim);
+    HMM_REQUIRE(n_rows > 0 && n_rows < (int64_t)0xFFFFFFFFll, HMM_E_INVALID, "cosine_topk_segmented_prefilter: n_rows out of range");
+    HMM_REQUIRE(n_segments >= 1 && k >= 1, HMM_E_INVALID, "cosine_topk_segmented_prefilter: need n_segments >= 1 and k >= 1");
+    HMM_REQUIRE(store_dev && shadow_dev && query_dev && seg_offsets_dev && idx_out_dev && sim_out_dev && n_out_dev && workspace_dev,
+                HMM_E_INVALID, "cosine_topk_segmented_prefilter: null pointer");
+    HMM_REQUIRE(workspace_bytes >= hmm_cosine_topk_segmented_prefilter_workspace_bytes(n_rows, n_segments, k), HMM_E_WORKSPACE,
+                "cosine_topk_segmented_prefilter: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* sims = static_cast<float*>(workspace_dev);
+    int64_t blocks = (n_rows + 127) / 128;                                  // 4 waves x 32 rows
+    if (blocks > kScanBlocks) blocks = kScanBlocks;
+    prefilter_sims_kernel<<<(unsigned)blocks, 256, 0, st>>>(static_cast<const uint4*>(shadow_dev), n_rows,
+                                                            reinterpret_cast<const float4*>(query_dev), sims);
+    HMM_LAUNCH_CHECK();
+    segment_prefilter_kernel<<<n_segments, 1024, 0, st>>>(sims, seg_offsets_dev, k, reinterpret_cast<const float4*>(store_dev),
+                                                          reinterpret_cast<const float4*>(query_dev), idx_out_dev, sim_out_dev, n_out_dev);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
 }

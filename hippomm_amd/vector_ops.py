@@ -115,10 +115,11 @@ class FeatureStore:
                    "hmm_cosine_topk_keys")
         return keys
 
-    def search_segments_device(self, query: torch.Tensor, seg_offsets: torch.Tensor, k: int):
+    def search_segments_device(self, query: torch.Tensor, seg_offsets: torch.Tensor, k: int, prefilter: bool = False):
         """Per-event top-k in one pass.  seg_offsets: int64 CUDA tensor (E+1,), row offsets of the events inside
         this store.  Returns CUDA tensors idx (E,k) int64 rows within each event (-1 padded), sims (E,k) fp32,
-        counts (E,) int32 = min(k, n_e)."""
+        counts (E,) int32 = min(k, n_e).  ``prefilter``: stream the bf16 shadow (built on first use) and re-score each event's
+        candidates on the fp32 rows -- the same outputs, bit for bit, for half the bytes (hmm_cosine_topk_segmented_prefilter)."""
         lib = _lib.load()
         dev = self.rows.device
         E = seg_offsets.numel() - 1
@@ -128,6 +129,14 @@ class FeatureStore:
         idx = torch.empty(E, k, dtype=torch.int64, device=dev)
         sims = torch.empty(E, k, dtype=torch.float32, device=dev)
         counts = torch.empty(E, dtype=torch.int32, device=dev)
+        if prefilter and len(self) > 0:
+            self.build_shadow()
+            _lib.check(lib.hmm_cosine_topk_segmented_prefilter(self.rows.data_ptr(), self._shadow.data_ptr(), len(self), FEATURE_DIM,
+                                                               query.data_ptr(), seg_offsets.data_ptr(), E, k, idx.data_ptr(),
+                                                               sims.data_ptr(), counts.data_ptr(), self._ws.data_ptr(),
+                                                               self._ws.numel(), _lib.stream_ptr()),
+                       "hmm_cosine_topk_segmented_prefilter")
+            return idx, sims, counts
         _lib.check(lib.hmm_cosine_topk_segmented(self.rows.data_ptr(), len(self), FEATURE_DIM, query.data_ptr(),
                                                  seg_offsets.data_ptr(), E, k, idx.data_ptr(), sims.data_ptr(),
                                                  counts.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
@@ -259,14 +268,14 @@ class EventStore(FeatureStore):
         self.offsets = torch.tensor(np.concatenate([[0], np.cumsum(self.lengths)]), dtype=torch.int64, device=rows.device)
         return self
 
-    def top_hits(self, query, k: int = 5, keep: int = 5):
+    def top_hits(self, query, k: int = 5, keep: int = 5, prefilter: bool = False):
         """The caller's whole step in one go (hippocampal_memory.py:3143-3153 + :3275-3277): top-k per event, then every hit of
         every event ranked by similarity and the best `keep` returned as [(event index, row inside the event, similarity)].
         The ranking runs on the device (a stable descending sort of the (E, k) similarities in event order, i.e. what Python's
         stable ``sorted(..., reverse=True)`` does to the list the reference builds event by event); only `keep` hits are read
         back.  NaN similarities (zero-norm rows) rank first, as they do per event."""
         q = _query_to_device(query, self.rows.device)
-        idx, sims, counts = self.search_segments_device(q, self.offsets, int(k))
+        idx, sims, counts = self.search_segments_device(q, self.offsets, int(k), prefilter)
         E = idx.shape[0]
         if E == 0:
             return []
@@ -280,10 +289,10 @@ class EventStore(FeatureStore):
         vals = sims.reshape(-1)[order].cpu().tolist()
         return list(zip(ev, rows, vals))
 
-    def top_k_per_event(self, query, k: int = 5):
+    def top_k_per_event(self, query, k: int = 5, prefilter: bool = False):
         """[(indices int64[k_e], sims float32[k_e]) for every event], each exactly what
         ``top_k_cosine_similarity(query, event_features, k)`` returns for that event."""
         q = _query_to_device(query, self.rows.device)
-        idx, sims, counts = self.search_segments_device(q, self.offsets, int(k))
+        idx, sims, counts = self.search_segments_device(q, self.offsets, int(k), prefilter)
         idx, sims, counts = idx.cpu().numpy(), sims.cpu().numpy(), counts.cpu().numpy()
         return [(idx[e, :counts[e]].astype(np.int64), sims[e, :counts[e]]) for e in range(len(self.lengths))]

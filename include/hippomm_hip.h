@@ -101,6 +101,15 @@ int    hmm_cosine_topk_prefilter(const float* store_dev, const void* shadow_dev,
                                  const float* query_dev, int k, int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
                                  int32_t* stats_out_dev, void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
 
+/* hmm_cosine_topk_segmented through the shadow: one pass over 2048 B per row for approximate similarities, per event the rows
+ * that can be among its k best (same bound) re-scored on the fp32 store.  Same outputs as hmm_cosine_topk_segmented, bit for
+ * bit (hippocampal_memory.py:3143-3153 semantics).  k > 64: the call IS hmm_cosine_topk_segmented. */
+size_t hmm_cosine_topk_segmented_prefilter_workspace_bytes(int64_t n_rows, int n_segments, int k);
+int    hmm_cosine_topk_segmented_prefilter(const float* store_dev, const void* shadow_dev, int64_t n_rows, int dim,
+                                           const float* query_dev, const int64_t* seg_offsets_dev, int n_segments, int k,
+                                           int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
+                                           void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
+
 /* Batched feature_search: the top-k of n_queries queries against the same store in ONE pass over it
  * (16 queries per pass; the Q x rows similarity block runs on the fp32 matrix cores, so a row is still read once from
  * HBM).  The reference calls top_k_cosine_similarity once per question (hippomm/utils/vector_ops.py:151-188 via

@@ -151,3 +151,46 @@ def test_full_size_1m_rows_identical_to_the_exact_scan():
     pick = torch.tensor([0, 1, 499_999, 999_999], device="cuda")
     want = (rows[pick] / rows[pick].norm(dim=1, keepdim=True)).to(torch.bfloat16)
     assert (sh[pick].float() - want.float()).abs().max().item() <= 2 ** -8 * want.float().abs().max().item()
+
+
+def _events(sizes, seed):
+    rng = np.random.default_rng(seed)
+    return [rng.standard_normal((n, 1024), dtype=np.float32) for n in sizes]
+
+
+@pytest.mark.parametrize("sizes,k", [([300, 1, 0, 57, 5, 4096, 4097, 2], 5), ([9000, 3, 12000], 32), ([40] * 200, 5), ([500] * 64, 5),
+                                     ([5000], 64), ([5000], 100)])
+def test_per_event_prefilter_equals_the_exact_per_event_scan(sizes, k):
+    """hmm_cosine_topk_segmented_prefilter vs hmm_cosine_topk_segmented: identical indices, similarity bits and counts for every
+    event -- empty and one-row events, events above one chunk, a tie and a NaN row inside an event, k above the prefilter's limit."""
+    from hippomm_amd.vector_ops import EventStore
+    events = _events(sizes, seed=len(sizes) * 7 + k)
+    if len(events) > 3 and events[3].shape[0] > 10:
+        events[3][7] = events[3][2]
+        events[3][9] = 0.0
+    es = EventStore(events)
+    q = torch.from_numpy(np.random.default_rng(1).standard_normal(1024, dtype=np.float32)).cuda()
+    i0, s0, c0 = es.search_segments_device(q, es.offsets, k)
+    i1, s1, c1 = es.search_segments_device(q, es.offsets, k, prefilter=True)
+    assert torch.equal(c0, c1) and torch.equal(i0, i1)
+    assert torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+
+
+def test_per_event_prefilter_on_events_of_near_identical_rows():
+    """Every event is one scene: 300 frames within 1e-3 of each other, so every row of an event is a candidate (more than the
+    candidate buffer for the large event) and the whole event is re-scored; the answer must still be the exact one."""
+    from hippomm_amd.vector_ops import EventStore
+    rng = np.random.default_rng(3)
+    sizes = [300, 2000, 40, 300]
+    events = []
+    for n in sizes:
+        c = rng.standard_normal(1024).astype(np.float32)
+        events.append(c + 1e-3 * rng.standard_normal((n, 1024), dtype=np.float32))
+    es = EventStore(events)
+    q = torch.from_numpy((events[1][5] + 0.3 * rng.standard_normal(1024)).astype(np.float32)).cuda()
+    for k in (5, 32):
+        i0, s0, c0 = es.search_segments_device(q, es.offsets, k)
+        i1, s1, c1 = es.search_segments_device(q, es.offsets, k, prefilter=True)
+        assert torch.equal(c0, c1) and torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    hits0, hits1 = es.top_hits(q, 5, 5), es.top_hits(q, 5, 5, prefilter=True)
+    assert hits0 == hits1

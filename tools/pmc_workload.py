@@ -44,8 +44,10 @@ for s in range(0, n, 125_000):
 store = FeatureStore(rows)
 q = torch.randn(1024, device=dev)
 q16 = torch.randn(16, 1024, device=dev)
+store.build_shadow()
 for _ in range(REPS):
     store.search_device(q, 32)
     store.search_multi_device(q16, 32)
+    store.search_prefiltered_device(q, 32)
 torch.cuda.synchronize()
 print("pmc workload done")
