@@ -103,7 +103,8 @@ int    hmm_cosine_topk_prefilter(const float* store_dev, const void* shadow_dev,
 
 /* hmm_cosine_topk_segmented through the shadow: one pass over 2048 B per row for approximate similarities, per event the rows
  * that can be among its k best (same bound) re-scored on the fp32 store.  Same outputs as hmm_cosine_topk_segmented, bit for
- * bit (hippocampal_memory.py:3143-3153 semantics).  k > 64: the call IS hmm_cosine_topk_segmented. */
+ * bit (hippocampal_memory.py:3143-3153 semantics).  k > 64, or events of fewer than 128 rows on average: the call IS
+ * hmm_cosine_topk_segmented. */
 size_t hmm_cosine_topk_segmented_prefilter_workspace_bytes(int64_t n_rows, int n_segments, int k);
 int    hmm_cosine_topk_segmented_prefilter(const float* store_dev, const void* shadow_dev, int64_t n_rows, int dim,
                                            const float* query_dev, const int64_t* seg_offsets_dev, int n_segments, int k,
