@@ -464,11 +464,34 @@ def retrieval_bench(rows, do_cpu):
     t_scan_pre = event_time_ms(lambda: events.search_segments_device(q, events.offsets, 5, prefilter=True), 10, warmup=2)
     ex, pre = events.search_segments_device(q, events.offsets, 5), events.search_segments_device(q, events.offsets, 5, prefilter=True)
     pre_same = bool(torch.equal(ex[0], pre[0]) and torch.equal(ex[1].view(torch.int32), pre[1].view(torch.int32)) and torch.equal(ex[2], pre[2]))
+    # the reference's loop UNCHANGED (hippocampal_memory.py:3143-3153): one top_k_cosine_similarity call per event with the event's
+    # host array, as a drop-in: uploaded per call, and with hippomm_amd.vector_ops.enable_store_cache() (resident from the 2nd call)
+    from hippomm_amd import vector_ops as vo
+    host_events = [rows[e * per_event:(e + 1) * per_event].cpu().numpy() for e in range(100)]
+    qh0 = q.cpu().numpy()
+
+    def loop():
+        t0 = time.perf_counter()
+        for ev in host_events:
+            vo.top_k_cosine_similarity(qh0, ev, 5)
+        return (time.perf_counter() - t0) / len(host_events) * 1e3
+    loop()
+    ms_upload = min(loop() for _ in range(3))
+    vo.enable_store_cache()
+    try:
+        loop()
+        ms_cached = min(loop() for _ in range(3))
+    finally:
+        vo.disable_store_cache()
+    del host_events
     out = {"what": "question -> tokenizer -> text tower (24 blocks, batch 1) -> top-5 per event over 2000 events x 500 rows "
                    "(one pass) -> best 5 hits on the host",
            "ms_end_to_end": round(sorted(t)[len(t) // 2] * 1e3, 3), "ms_text_tower": round(t_tower, 3),
            "ms_per_event_scan_all_events": round(t_scan, 3), "events": n_events, "rows": n_events * per_event,
            "ms_per_event_scan_bf16_prefilter": round(t_scan_pre, 3), "prefilter_identical_to_fp32_scan": pre_same,
+           "unchanged_reference_loop_ms_per_event": {"numpy_store_uploaded_per_call": round(ms_upload, 4),
+                                                     "with_enable_store_cache": round(ms_cached, 4), "events_timed": 100,
+                                                     "rows_per_event": per_event},
            "ms_end_to_end_ranked_on_device": round(sorted(t2)[len(t2) // 2] * 1e3, 3),
            "device_ranking_equals_host_ranking": [(e, i) for e, i, _ in top2] == [(e, i) for _, e, i in top]}
     if do_cpu:

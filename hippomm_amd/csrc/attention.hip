@@ -21,11 +21,12 @@
 
 namespace hmm {
 
+HMM_TUNABLE(int, g_attn_q_split, 1)      // probe build: 0 = never split a (sample, head)'s queries over workgroups (A/B)
 
 template <int DH, int NKT>
 __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n_img, int T, int Lk, int H,
-    const float* __restrict__ bias_k, const float* __restrict__ bias_v, float scale_log2e, int causal) {
+    const float* __restrict__ bias_k, const float* __restrict__ bias_v, float scale_log2e, int causal, int q_parts) {
     using C = AttnCfg<DH, NKT>;
     constexpr int NT = kAttnWaves * 64;
     constexpr int CPR = DH / 8;                      // 16-B chunks per K/V row
@@ -42,8 +43,11 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
     // The images are walked backwards: the producer (QKV GEMM) wrote the last images last, so they are the
     // ones still resident in the 256-MiB Infinity Cache when this kernel starts.
     // causal (text tower): key j is visible to query i iff j <= i.
-    const int n = blockIdx.x >> 3;
-    const int b_lin = (blockIdx.x & 7) + 8 * (n / H);
+    // q_parts > 1 (few samples): consecutive blocks are the query parts of one (sample, head)
+    const int q_part = blockIdx.x % q_parts;
+    const int blk = blockIdx.x / q_parts;
+    const int n = blk >> 3;
+    const int b_lin = (blk & 7) + 8 * (n / H);
     const int h = n % H;
     if (b_lin >= n_img) return;
     const int b = n_img - 1 - b_lin;
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
     // this wave's first query fragments: issued before the K/V staging so that they ride along
     bf16x8 qf[C::KS];
     {
-        const int qrow = wave * 32 + r;
+        const int qrow = (q_part + q_parts * wave) * 32 + r;
         const int qr = qrow < T ? qrow : T - 1;
         const bf16_t* qp = base + (size_t)qr * row_stride + hh * 8;
 #pragma unroll
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
         return *reinterpret_cast<const bf16x8*>(base + (size_t)row * row_stride + hh * 8 + ks * 16);
     };
     attention_core<DH, NKT>(k_lds, v_lds, reinterpret_cast<float*>(smem + C::K_BYTES + C::V_BYTES), load_q, qf,
-                            out + (size_t)b * T * D + h * DH, T, Lk, D, scale_log2e, causal);
+                            out + (size_t)b * T * D + h * DH, T, Lk, D, scale_log2e, causal, q_part, q_parts);
 }
 
 template <int DH, int NKT>
@@ -112,8 +116,13 @@ static int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int T, in
     auto kern = attention_kernel<DH, NKT>;
     HMM_ENSURE_DYN_LDS(kern, C::LDS);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
-    const int grid = 8 * ((batch + 7) / 8) * H;
-    kern<<<grid, kAttnWaves * 64, C::LDS, st>>>(qkv, out, batch, T, Lk, H, bias_k, bias_v, scale_log2e, causal ? 1 : 0);
+    const int wgs = 8 * ((batch + 7) / 8) * H;
+    // few samples: split the query tiles of a (sample, head) over 2 or 4 workgroups while that still fits the chip (each part
+    // stages the head's K and V itself: 82 KB from L2); same bits (attention_core.h)
+    int q_parts = 1;
+    if (g_attn_q_split && T > 64)
+        while (q_parts < 4 && wgs * q_parts * 2 <= kNumCU) q_parts *= 2;
+    kern<<<wgs * q_parts, kAttnWaves * 64, C::LDS, st>>>(qkv, out, batch, T, Lk, H, bias_k, bias_v, scale_log2e, causal ? 1 : 0, q_parts);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }

@@ -53,11 +53,15 @@ constexpr int kAttnWaves = 8;
 
 // k_lds / v_lds: the images (rows >= Lk zero-filled); part: C::X_BYTES of LDS scratch; load_q(row, ks) -> the bf16x8
 // fragment d = 16 ks + 8 hh .. + 7 of query `row` (row < T) for this lane's hh = lane >> 5; qf: the fragments of query
-// tile `wave`, preloaded by the caller; out_head = out + sample * T * D + head * DH.  Ends with the results stored.
+// tile `first_qt`, preloaded by the caller; out_head = out + sample * T * D + head * DH.  Ends with the results stored.
+// Query split (few samples: one workgroup per (sample, head) leaves most CUs idle): this workgroup is part q_part of q_parts
+// and takes the 32-query tiles q_part + q_parts * (wave + 8 i); the single extra query (T = 8 * 32 + 1) goes with part 0.
+// A query tile is computed by one wave on its own whichever workgroup holds it: the same bits for every q_parts.
 template <int DH, int NKT, class QLoad>
 __device__ __forceinline__ void attention_core(const char* k_lds, const char* v_lds, float* part, QLoad load_q,
                                                bf16x8 (&qf)[AttnCfg<DH, NKT>::KS], bf16_t* __restrict__ out_head,
-                                               int T, int Lk, int D, float scale_log2e, bool causal HMM_ATTN_PROBE_PARAM) {
+                                               int T, int Lk, int D, float scale_log2e, bool causal, int q_part = 0,
+                                               int q_parts = 1 HMM_ATTN_PROBE_PARAM) {
     using C = AttnCfg<DH, NKT>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,9 +81,10 @@ __device__ __forceinline__ void attention_core(const char* k_lds, const char* v_
     // query, that query is instead processed cooperatively below: one key tile per wave.
     const bool coop = (nqt == kAttnWaves + 1) && (T - kAttnWaves * 32 == 1) && !causal;
     const int nqt_main = coop ? kAttnWaves : nqt;
-    for (int qt = wave; qt < nqt_main; qt += kAttnWaves) {
+    const int first_qt = q_part + q_parts * wave;
+    for (int qt = first_qt; qt < nqt_main; qt += kAttnWaves * q_parts) {
         const int qrow = qt * 32 + r;
-        if (qt != wave) {                                   // later tiles reload their queries
+        if (qt != first_qt) {                               // later tiles reload their queries
             const int qr = qrow < T ? qrow : T - 1;
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) qf[ks] = load_q(qr, ks);
@@ -211,7 +216,7 @@ __device__ __forceinline__ void attention_core(const char* k_lds, const char* v_
     }
 
     HMM_ATTN_STAMP(3)
-    if (coop) {
+    if (coop && q_part == 0) {                              // workgroup-uniform
         const int xq = T - 1;                                  // the extra query row: every column of the B operand = this query
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) qf[ks] = load_q(xq, ks);

@@ -226,14 +226,23 @@ __global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* _
     }
     const float q_len = sqrtf(wave_sum(qs));
     const int m_pad = pow2_at_least(m, 64);
-    for (int c = wave; c < m_pad; c += 16) {
-        uint64_t key = 0ull;
-        if (c < m) {
-            const uint32_t row = cand_row[c];
-            const float sim = exact_row_sim(store + (int64_t)row * 256 + lane, q, q_len);
-            key = ((uint64_t)order_bits(sim) << 32) | (uint64_t)row;
+    for (int t = m + tid; t < m_pad; t += 1024) s[t] = 0ull;
+    for (int c0 = wave * 4; c0 < m; c0 += 64) {                               // four candidates per wave and round: one latency per round
+        const int nr = m - c0 < 4 ? m - c0 : 4;                               // wave-uniform
+        const float4* rp[4];
+        uint32_t row[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            row[i] = cand_row[c0 + (i < nr ? i : 0)];
+            rp[i] = store + (int64_t)row[i] * 256 + lane;
         }
-        if (lane == 0) s[c] = key;
+        float sim[4];
+        exact_row_sim4(rp, nr, q, q_len, sim);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nr) s[c0 + i] = ((uint64_t)order_bits(sim[i]) << 32) | (uint64_t)row[i];
+        }
     }
     __syncthreads();
     top64_desc(s, m_pad);

@@ -47,6 +47,31 @@ __device__ __forceinline__ float exact_row_sim(const float4* row_lane, const flo
     return d / (sqrtf(s) * q_len);
 }
 
+// Up to four rows at once: all sixteen loads first (one memory latency for the group), then each row's arithmetic exactly as
+// exact_row_sim has it -- the same bits.  rows[i] for i >= n are not touched; sim[i] is valid for i < n.
+__device__ __forceinline__ void exact_row_sim4(const float4* const (&row_lane)[4], int n, const float4 (&q)[4], float q_len,
+                                               float (&sim)[4]) {
+    float4 a[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < n) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[i][j] = ld16<true>(row_lane[i] + j * 64);
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sim[i] = 0.f;
+        if (i < n) {
+            float d = 0.f, s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fma4(d, s, a[i][j], q[j]);
+            d = wave_sum(d);
+            s = wave_sum(s);
+            sim[i] = d / (sqrtf(s) * q_len);
+        }
+    }
+}
+
 int cosine_topk_if(const int* run_if, const float* store, int64_t n, const float* query, int k, int64_t* idx_out, float* sim_out,
                    int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t st);
 

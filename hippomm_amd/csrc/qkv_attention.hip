@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
     attention_core<kDH, G::NKT>(k_lds, v_lds, reinterpret_cast<float*>(smem + P::XOff), load_q, qf,
                                 out + (size_t)b * kT * kD + h * kDH, kT, kT + (G::BIAS_KV ? 1 : 0), kD, scale_log2e, false
 #ifdef HMM_PROBE
-                                , stamps ? stamps + (size_t)blockIdx.x * 16 : nullptr
+                                , 0, 1, stamps ? stamps + (size_t)blockIdx.x * 16 : nullptr
 #endif
                                 );
 #ifdef HMM_PROBE

@@ -162,3 +162,38 @@ def test_full_size_properties_1m_rows():
     o_idx, o_sims = top_k_cosine_similarity_oracle(q.cpu().numpy(), sub, k)
     assert pick[o_idx].tolist() == idx_h.tolist()
     np.testing.assert_allclose(sims_h, o_sims, rtol=0, atol=SIM_ATOL)
+
+
+def test_store_cache_keeps_numpy_stores_resident_and_notices_what_it_can():
+    """enable_store_cache(): the reference's unchanged per-event loop passes the same host arrays question after question; they
+    are served from HBM from the second call on, rebuilt when the array object, its buffer or a sampled element changed, released
+    when the host array dies, and the feature is off unless asked for."""
+    import gc
+    from hippomm_amd import vector_ops as vo
+    rng = np.random.default_rng(31)
+    events = [rng.standard_normal((n, 1024)).astype(np.float64 if i % 2 else np.float32) for i, n in enumerate((300, 41, 1000))]
+    q = rng.standard_normal(1024, dtype=np.float32)
+    want = [vo.top_k_cosine_similarity(q, ev, 5) for ev in events]
+    assert vo._STORE_CACHE is None                                          # off by default
+    cache = vo.enable_store_cache(max_bytes=64 << 20)
+    try:
+        for rnd in range(3):
+            for ev, (wi, ws) in zip(events, want):
+                idx, sims = vo.top_k_cosine_similarity(q, ev, 5)
+                assert idx.tolist() == wi.tolist() and sims.dtype == ws.dtype and np.array_equal(sims, ws)
+        assert (cache.misses, cache.hits) == (3, 6)
+        events[0][0, 0] += 1.0                                              # row 0 is always in the fingerprint sample
+        idx, sims = vo.top_k_cosine_similarity(q, events[0], 5)
+        with np.errstate(invalid="ignore"):
+            o_idx, o_sims = top_k_cosine_similarity_oracle(q, events[0], 5)
+        assert cache.misses == 4 and idx.tolist() == o_idx.tolist()
+        held = cache.bytes
+        del events[2], ev                                                   # `ev` still names the last event of the loop above
+        gc.collect()
+        assert cache.bytes == held - 1000 * 4096 and len(cache.entries) == 2   # the HBM copy went with the host array
+        big = rng.standard_normal((20000, 1024), dtype=np.float32)          # 80 MB > max_bytes: evicts the others, still answers
+        vo.top_k_cosine_similarity(q, big, 5)
+        assert len(cache.entries) == 1
+    finally:
+        vo.disable_store_cache()
+    assert vo._STORE_CACHE is None

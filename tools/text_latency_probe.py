@@ -15,6 +15,7 @@ set_stages = setter(lib, "g_gemm_small_stages")
 set_64 = setter(lib, "g_gemm_small_64")
 set_32 = setter(lib, "g_gemm_small_32")
 set_deepk = setter(lib, "g_gemm_deepk")
+set_qsplit = setter(lib, "g_attn_q_split")
 from hippomm_amd.encoder import HipTower, synthetic_state_dict   # noqa: E402
 
 rows = []
@@ -56,10 +57,11 @@ for kind, batches in (("text", (1, 2, 3, 4, 8, 16, 64)), ("vision", (1, 2, 4, 8,
             x = torch.randn(B, 3, 224, 224, device="cuda")
         rec = {"tower": kind, "batch": B}
         outs = []
-        for tag, auto, stages, t64, t32, dk in (("tiled", 0, 2, 0, 0, 0), ("ring128", 0, 4, 0, 0, 0), ("ring64", 0, 4, 512, 0, 0),
-                                                ("ring64_sliver", 1, 4, 512, 0, 0), ("round3_product", 1, 4, 512, 400, 0),
-                                                ("product", 1, 4, 512, 400, 1)):
+        for tag, auto, stages, t64, t32, dk, qs in (("tiled", 0, 2, 0, 0, 0, 0), ("ring128", 0, 4, 0, 0, 0, 0), ("ring64", 0, 4, 512, 0, 0, 0),
+                                                    ("ring64_sliver", 1, 4, 512, 0, 0, 0), ("round3_product", 1, 4, 512, 400, 0, 0),
+                                                    ("deepk", 1, 4, 512, 400, 1, 0), ("product", 1, 4, 512, 400, 1, 1)):
             set_deepk(dk)
+            set_qsplit(qs)
             set_auto(auto)
             set_stages(stages)
             set_64(t64)
