@@ -14,8 +14,8 @@
 //            <= 2^-8 ||x|| ||q||, i.e. |s~ - s| <= 2^-8 (1 + 2^-8) + fp32 summation noise (~3e-6 for both kernels) < eps = 0.0040.
 //            If row r is in the exact top-k then s_r >= the k-th largest s >= t - eps (k rows have s >= s~ - eps >= t - eps), hence
 //            s~_r >= t - 2 eps: r is a candidate.  A NaN s~ (zero-norm row, NaN query) ranks first, as NaN similarities do.
-//   Fallback.  The candidate set is complete only if no block's list is saturated above the threshold (its k-th entry >= t - 2 eps
-//            means the block may have dropped candidates) and fits the re-scoring buffer; otherwise pass 2 raises a flag and the
+//   Fallback.  The candidate set is complete only if no block's list is saturated above the threshold (a list keeps max(2k, 16) <= 64
+//            entries; its LAST entry >= t - 2 eps means the block may have dropped candidates) and fits the re-scoring buffer; otherwise pass 2 raises a flag and the
 //            exact scan (scan_topk_kernel + topk_final_kernel, conditional on that flag) produces the answer.  Either way the
 //            outputs are those of hmm_cosine_topk.  Stores of many near-ties (thousands of rows within 0.8 % of the k-th best)
 //            take the fallback: 0.3 ms wasted; random or video-like stores do not.
@@ -447,6 +447,8 @@ extern "C" int hmm_cosine_topk_prefilter(const float* store_dev, const void* sha
     HMM_REQUIRE(store_dev && shadow_dev && query_dev && idx_out_dev && sim_out_dev && workspace_dev, HMM_E_INVALID,
                 "cosine_topk_prefilter: null pointer");
     HMM_REQUIRE(k >= 1, HMM_E_INVALID, "cosine_topk_prefilter: k must be >= 1, got %d", k);
+    HMM_REQUIRE(n_rows >= 1 && n_rows < (int64_t)0xFFFFFFFFll, HMM_E_INVALID, "cosine_topk_prefilter: n_rows=%lld out of range",
+                (long long)n_rows);
     HMM_REQUIRE(((uintptr_t)store_dev & 15) == 0 && ((uintptr_t)shadow_dev & 15) == 0 && ((uintptr_t)query_dev & 15) == 0,
                 HMM_E_INVALID, "cosine_topk_prefilter: store / shadow / query must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
