@@ -6,13 +6,14 @@
 //            built once per store by hmm_shadow_store_build;
 //   pass 1   prefilter_topk_kernel streams the shadow: s~_r = dot(shadow_r, q) / ||q|| in fp32, block-local top-k of the s~ keys
 //            exactly as scan_topk_kernel keeps them (cosine_topk.hip);
-//   pass 2   prefilter_final_kernel (one workgroup): t = the k-th largest s~ over all blocks; every row whose exact similarity
-//            can be among the k largest has s~_r >= t - 2 eps (below); those rows are re-scored on the fp32 store with the
+//   pass 2   prefilter_final_kernel (one workgroup): t = the k-th largest block maximum of s~, a lower bound of the k-th largest s~
+//            (k different rows reach it); every row whose exact similarity can be among the k largest has s~_r >= t - 2 eps
+//            (below); those rows are re-scored on the fp32 store with the
 //            arithmetic of scan_topk_kernel (exact_row_sim: same loads, same fma order, same wave reduction, same division) and
 //            the k best of them are the answer.
 //   Error bound.  bf16 has an 8-bit significand: x~ = x (1 + d), |d| <= 2^-8, so |dot(x~, q) - dot(x, q)| <= 2^-8 sum |x_i q_i|
 //            <= 2^-8 ||x|| ||q||, i.e. |s~ - s| <= 2^-8 (1 + 2^-8) + fp32 summation noise (~3e-6 for both kernels) < eps = 0.0040.
-//            If row r is in the exact top-k then s_r >= the k-th largest s >= t - eps (k rows have s >= s~ - eps >= t - eps), hence
+//            If row r is in the exact top-k then s_r >= the k-th largest s >= t - eps (k rows have s~ >= t, so s >= t - eps), hence
 //            s~_r >= t - 2 eps: r is a candidate.  A NaN s~ (zero-norm row, NaN query) ranks first, as NaN similarities do.
 //   Fallback.  The candidate set is complete only if no block's list is saturated above the threshold (a list keeps max(2k, 16) <= 64
 //            entries; its LAST entry >= t - 2 eps means the block may have dropped candidates) and fits the re-scoring buffer; otherwise pass 2 raises a flag and the
@@ -155,7 +156,9 @@ __global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* _
     __shared__ int n_cand, n_sat, n_hot;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { n_cand = 0; n_sat = 0; n_hot = 0; }
-    // the k-th largest approximate key: the k lists with the largest maxima hold it (see topk_final_kernel)
+    // A lower bound of the k-th largest approximate key: the k-th largest BLOCK MAXIMUM (k distinct rows reach it; the k best rows
+    // of 2048 interleaved blocks sit in k different blocks nearly always, so it is the k-th largest key itself or a hair below).
+    // A lower threshold only adds candidates; it saves gathering and ranking the k winning lists (two dependent round trips).
     const int n2 = pow2_at_least(n_blocks, 64);
     uint64_t own[kScanBlocks / 1024];                                         // this thread's block maxima, kept for the hot-list pass
 #pragma unroll
@@ -166,23 +169,7 @@ __global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* _
     }
     __syncthreads();
     top64_desc(mx, n2);
-    const int n_win = n_blocks < k ? n_blocks : k;
-    const int m2 = pow2_at_least(n_win * kk, 64);
-    for (int t = tid; t < m2; t += 1024) {
-        uint64_t key = 0ull;
-        if (t < n_win * kk) {
-            const uint64_t top = mx[t / kk];
-            if (top != 0ull) {
-                const int64_t row = (int64_t)(top & 0xFFFFFFFFull);
-                const int blk = (int)(((row >> 2) % n_waves) >> 2);           // rows are dealt four per wave
-                key = lists[(int64_t)blk * kk + (t % kk)];
-            }
-        }
-        s[t] = key;
-    }
-    __syncthreads();
-    top64_desc(s, m2);
-    const uint64_t kth = s[k - 1];                                            // 0 = fewer than k rows in all (launcher excludes it)
+    const uint64_t kth = mx[k - 1];                                           // 0 = fewer than k blocks hold a row: the exact scan answers
     const float t_lo = order_bits_inverse((uint32_t)(kth >> 32)) - 2.0f * kPrefilterEps;
     const uint32_t thr = order_bits(t_lo);                                    // NaN k-th -> 0xFFFFFFFF: only NaN rows pass
     __syncthreads();
