@@ -194,3 +194,32 @@ def test_per_event_prefilter_on_events_of_near_identical_rows():
         assert torch.equal(c0, c1) and torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
     hits0, hits1 = es.top_hits(q, 5, 5), es.top_hits(q, 5, 5, prefilter=True)
     assert hits0 == hits1
+
+
+def test_error_codes_through_the_c_abi():
+    """Bad arguments come back as status codes with a message (include/hippomm_hip.h conventions), never as a crash."""
+    import ctypes as C
+    from hippomm_amd import _lib as L
+    lib = L.load()
+    n, k = 20000, 5
+    rows = torch.randn(n, 1024, device="cuda")
+    q = torch.randn(1024, device="cuda")
+    shadow = torch.empty(lib.hmm_shadow_store_bytes(n), dtype=torch.uint8, device="cuda")
+    assert lib.hmm_shadow_store_bytes(n) == n * 2048 and lib.hmm_shadow_store_bytes(0) == 0
+    idx = torch.empty(k, dtype=torch.int64, device="cuda"); sims = torch.empty(k, device="cuda")
+    n_out = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(lib.hmm_cosine_topk_prefilter_workspace_bytes(n, k), dtype=torch.uint8, device="cuda")
+    st = L.stream_ptr()
+    assert lib.hmm_shadow_store_build(rows.data_ptr(), n, 1024, shadow.data_ptr(), shadow.numel(), st) == 0
+    assert lib.hmm_shadow_store_build(rows.data_ptr(), n, 512, shadow.data_ptr(), shadow.numel(), st) == -1          # HMM_E_INVALID
+    assert lib.hmm_shadow_store_build(rows.data_ptr(), n, 1024, shadow.data_ptr(), shadow.numel() - 1, st) == -2     # HMM_E_WORKSPACE
+    assert b"shadow buffer" in lib.hmm_last_error()
+    call = lambda **kw: lib.hmm_cosine_topk_prefilter(kw.get("store", rows.data_ptr()), kw.get("shadow", shadow.data_ptr()), n, 1024,
+                                                      q.data_ptr(), kw.get("k", k), idx.data_ptr(), sims.data_ptr(), n_out.data_ptr(),
+                                                      None, ws.data_ptr(), kw.get("ws_bytes", ws.numel()), st)
+    assert call() == 0 and int(n_out.item()) == k
+    assert call(ws_bytes=1024) == -2
+    assert call(k=0) == -1 and call(shadow=None) == -1
+    assert call(store=rows.data_ptr() + 4) == -1 and b"aligned" in lib.hmm_last_error()
+    with pytest.raises(L.HippoMMHipError):
+        L.check(call(k=-3), "hmm_cosine_topk_prefilter")
