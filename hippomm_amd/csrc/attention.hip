@@ -117,11 +117,11 @@ static int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int T, in
     HMM_ENSURE_DYN_LDS(kern, C::LDS);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
     const int wgs = 8 * ((batch + 7) / 8) * H;
-    // few samples: split the query tiles of a (sample, head) over 2 or 4 workgroups while that still fits the chip (each part
-    // stages the head's K and V itself: 82 KB from L2); same bits (attention_core.h)
-    int q_parts = 1;
-    if (g_attn_q_split && T > 64)
-        while (q_parts < 4 && wgs * q_parts * 2 <= kNumCU) q_parts *= 2;
+    // a handful of samples: the query tiles of a (sample, head) go to TWO workgroups while the launch still fits the chip (each
+    // part stages the head's K and V itself: 82 KB from L2); same bits (attention_core.h).  Measured (tools/text_latency_probe.py):
+    // one frame 2.46 -> 2.39 ms, one audio segment 0.712 -> 0.696; four parts are slower (2.63 ms), and so is any split of the
+    // text tower's three query tiles (one question 1.04 -> 1.15 ms), hence T > 128.
+    const int q_parts = (g_attn_q_split && T > 128 && wgs * 2 <= kNumCU) ? 2 : 1;
     kern<<<wgs * q_parts, kAttnWaves * 64, C::LDS, st>>>(qkv, out, batch, T, Lk, H, bias_k, bias_v, scale_log2e, causal ? 1 : 0, q_parts);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
