@@ -781,8 +781,13 @@ static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* 
         return launch_gemm_ring32_epi(A, W, bias, C, M, N, K, epi, st);
     }
     if (g_gemm_small_64 &&
-        (long)((M + 63) / 64) * (N / 64) <= (tail ? g_gemm_tail_64 : g_gemm_small_64))
+        (long)((M + 63) / 64) * (N / 64) <= (tail ? g_gemm_tail_64 : g_gemm_small_64)) {
+        // at most one 64x64 tile per CU: the deep-K ring (96 KiB, one workgroup per CU anyway) -- one frame's fc2 24.5 -> 21.9 us,
+        // its out-proj 8.6 -> 8.0 (cold weights, tools/deepk_probe.py); with more tiles than CUs two plain-ring workgroups per CU win
+        if (g_gemm_deepk && !tail && epi <= HMM_EPI_F32 && (K >> 6) % 2 == 0 && K >= 1024 && (long)((M + 63) / 64) * (N / 64) <= kNumCU)
+            return launch_gemm_ringk_epi<64, 3, 2>(A, W, bias, C, M, N, K, epi, st);
         return launch_gemm_ring64_epi(A, W, bias, C, M, N, K, epi, st);
+    }
     return launch_gemm_ring128_epi(A, W, bias, C, M, N, K, epi, st);
 }
 
@@ -840,6 +845,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         case HMM_GEMM_TILE_128x128_RING: return launch_gemm_ring128_epi(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_64x64_RING:   return launch_gemm_ring64_epi(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_32x32_RING:   return launch_gemm_ring32_epi(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_64x64_RING_K2: return launch_gemm_ringk_epi<64, 3, 2>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_32x32_RING_K2: return launch_gemm_ringk_epi<32, 4, 2>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_32x32_RING_K4: return launch_gemm_ringk_epi<32, 4, 4>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_256x256_PP: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, st);
