@@ -21,6 +21,7 @@
 
 namespace hmm {
 
+HMM_TUNABLE(int, g_attn_short_keys, 1)   // probe build: 0 = the text tower's 77 keys on the eight-tile instantiation (A/B, bit equality)
 HMM_TUNABLE(int, g_attn_q_split, 1)      // probe build: 0 = never split a (sample, head)'s queries over workgroups (A/B)
 
 template <int DH, int NKT>
@@ -244,6 +245,9 @@ int attention_bf16(const bf16_t* qkv, bf16_t* out, int batch, int tokens, int he
     const int Lk = tokens + (bias_k ? 1 : 0);
     HMM_REQUIRE(!(causal && bias_k), HMM_E_INVALID, "attention: causal mask with bias_kv is not defined here");
     if (head_dim == 80 && Lk <= 288) return launch_attention<80, 9>(qkv, out, batch, tokens, Lk, heads, bias_k, bias_v, st, causal);
+    // 77 text tokens fit three key tiles: the eight-tile instantiation would compute five fully masked tiles per query tile (their
+    // probabilities are exactly 0 and their rescale factors exactly 1, so both instantiations give the same bits)
+    if (g_attn_short_keys && head_dim == 64 && Lk <= 96) return launch_attention<64, 3>(qkv, out, batch, tokens, Lk, heads, bias_k, bias_v, st, causal);
     if (head_dim == 64 && Lk <= 256) return launch_attention<64, 8>(qkv, out, batch, tokens, Lk, heads, bias_k, bias_v, st, causal);
     set_error("attention: unsupported head_dim=%d / keys=%d (built: 80 x <=288 keys, 64 x <=256 keys)", head_dim, Lk);
     return HMM_E_INVALID;

@@ -16,6 +16,7 @@ set_64 = setter(lib, "g_gemm_small_64")
 set_32 = setter(lib, "g_gemm_small_32")
 set_deepk = setter(lib, "g_gemm_deepk")
 set_qsplit = setter(lib, "g_attn_q_split")
+set_short = setter(lib, "g_attn_short_keys")
 from hippomm_amd.encoder import HipTower, synthetic_state_dict   # noqa: E402
 
 rows = []
@@ -62,6 +63,7 @@ for kind, batches in (("text", (1, 2, 3, 4, 8, 16, 64)), ("vision", (1, 2, 4, 8,
                                                     ("deepk", 1, 4, 512, 400, 1, 0), ("product", 1, 4, 512, 400, 1, 1)):
             set_deepk(dk)
             set_qsplit(qs)
+            set_short(1 if tag == "product" else 0)
             set_auto(auto)
             set_stages(stages)
             set_64(t64)
