@@ -6,16 +6,15 @@
 //            built once per store by hmm_shadow_store_build;
 //   pass 1   prefilter_topk_kernel streams the shadow: s~_r = dot(shadow_r, q) / ||q|| in fp32, block-local top-k of the s~ keys
 //            exactly as scan_topk_kernel keeps them (cosine_topk.hip);
-//   pass 2   prefilter_final_kernel (one workgroup): t = the k-th largest block maximum of s~, a lower bound of the k-th largest s~
-//            (k different rows reach it); every row whose exact similarity can be among the k largest has s~_r >= t - 2 eps
-//            (below); those rows are re-scored on the fp32 store with the
+//   pass 2   prefilter_final_kernel (one workgroup): t = the k-th largest s~ over all blocks; every row whose exact similarity
+//            can be among the k largest has s~_r >= t - 2 eps (below); those rows are re-scored on the fp32 store with the
 //            arithmetic of scan_topk_kernel (exact_row_sim: same loads, same fma order, same wave reduction, same division) and
 //            the k best of them are the answer.
 //   Error bound.  bf16 has an 8-bit significand: x~ = x (1 + d), |d| <= 2^-8, so |dot(x~, q) - dot(x, q)| <= 2^-8 sum |x_i q_i|
 //            <= 2^-8 ||x|| ||q||, i.e. |s~ - s| <= 2^-8 (1 + 2^-8) + fp32 summation noise (~3e-6 for both kernels) < eps = 0.0040.
 //            If row r is in the exact top-k then s_r >= the k-th largest s >= t - eps (k rows have s~ >= t, so s >= t - eps), hence
 //            s~_r >= t - 2 eps: r is a candidate.  A NaN s~ (zero-norm row, NaN query) ranks first, as NaN similarities do.
-//   Fallback.  The candidate set is complete only if no block's list is saturated above the threshold (a list keeps max(2k, 16) <= 64
+//   Fallback.  The candidate set is complete only if no block's list is saturated above the threshold (a list keeps max(2k, 32) <= 64
 //            entries; its LAST entry >= t - 2 eps means the block may have dropped candidates) and fits the re-scoring buffer; otherwise pass 2 raises a flag and the
 //            exact scan (scan_topk_kernel + topk_final_kernel, conditional on that flag) produces the answer.  Either way the
 //            outputs are those of hmm_cosine_topk.  Stores of many near-ties (thousands of rows within 0.8 % of the k-th best)
@@ -72,8 +71,11 @@ __device__ __forceinline__ float dot8_bf16(const uint4& x, const float4& qa, con
 }
 
 // ---- pass 1: stream the shadow, block-local top-k of the approximate keys ------------------------------------------------------
-// Rows are dealt four at a time, wave after wave (row r belongs to wave (r / 4) % n_waves), so neighbouring rows -- near-duplicate
-// frames of a video -- spread over the blocks instead of saturating one block's list.  8 x 16 B in flight per lane.
+// Rows are dealt four at a time, wave after wave (row r belongs to wave (r / 4) % n_waves): a block reads 32 KiB contiguous per
+// iteration and takes 16 consecutive rows of every band of 32 768, so a run of neighbouring rows -- the near-identical frames of
+// one scene of a video -- puts at most 16 candidates into one block's list, which keeps at least 32 entries (prefilter_list_len):
+// contiguous scenes of any length do not saturate a list.  (Spreading consecutive groups over different blocks, or dealing one
+// row per wave, streams 12 % slower -- four distant pieces per block and iteration instead of one run -- for no fewer fallbacks.)
 __global__ __launch_bounds__(256) void prefilter_topk_kernel(const uint4* __restrict__ shadow, int64_t n_rows,
                                                              const float4* __restrict__ query, int k,
                                                              uint64_t* __restrict__ out) {
@@ -101,13 +103,13 @@ __global__ __launch_bounds__(256) void prefilter_topk_kernel(const uint4* __rest
     const int64_t iters = (n_rows + n_waves * 4 - 1) / (n_waves * 4);
     const int compact_every = (kFusedCap - k) / 16;                          // 16 rows per block per iteration
     for (int64_t it = 0; it < iters; ++it) {
-        const int64_t r = wave * 4 + it * n_waves * 4;
-        const int have = r >= n_rows ? 0 : (n_rows - r >= 4 ? 4 : (int)(n_rows - r));      // wave-uniform
+        const int64_t r0 = wave * 4 + it * n_waves * 4;                      // this wave's group of four rows
+        const int have = r0 >= n_rows ? 0 : (n_rows - r0 >= 4 ? 4 : (int)(n_rows - r0));             // wave-uniform
         if (have) {
             uint4 x[4][2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint4* p = shadow + (r + (i < have ? i : 0)) * 128 + lane;
+                const uint4* p = shadow + (r0 + (i < have ? i : 0)) * 128 + lane;
                 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
                 const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 64));
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void prefilter_topk_kernel(const uint4* __rest
                 const int pos = atomicAdd(&count, have);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (i < have) cand[pos + i] = ((uint64_t)order_bits(d[i] * inv_qlen) << 32) | (uint64_t)(uint32_t)(r + i);
+                    if (i < have) cand[pos + i] = ((uint64_t)order_bits(d[i] * inv_qlen) << 32) | (uint64_t)(uint32_t)(r0 + i);
             }
         }
         if ((it + 1) % compact_every == 0 || it + 1 == iters) {              // block-uniform
@@ -156,9 +158,10 @@ __global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* _
     __shared__ int n_cand, n_sat, n_hot;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { n_cand = 0; n_sat = 0; n_hot = 0; }
-    // A lower bound of the k-th largest approximate key: the k-th largest BLOCK MAXIMUM (k distinct rows reach it; the k best rows
-    // of 2048 interleaved blocks sit in k different blocks nearly always, so it is the k-th largest key itself or a hair below).
-    // A lower threshold only adds candidates; it saves gathering and ranking the k winning lists (two dependent round trips).
+    // the k-th largest approximate key: the k lists with the largest maxima hold the k largest keys (every list keeps kk >= k
+    // entries).  (The k-th largest block MAXIMUM is a cheaper lower bound -- two dependent round trips fewer -- but when the k best
+    // rows sit in fewer than k blocks, as the frames of one scene do, it falls to the background level and thousands of rows
+    // become candidates: measured, 1/3 of the queries of a scene-structured store then took the exact-scan fallback.)
     const int n2 = pow2_at_least(n_blocks, 64);
     uint64_t own[kScanBlocks / 1024];                                         // this thread's block maxima, kept for the hot-list pass
 #pragma unroll
@@ -169,7 +172,23 @@ __global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* _
     }
     __syncthreads();
     top64_desc(mx, n2);
-    const uint64_t kth = mx[k - 1];                                           // 0 = fewer than k blocks hold a row: the exact scan answers
+    const int n_win = n_blocks < k ? n_blocks : k;
+    const int m2 = pow2_at_least(n_win * kk, 64);
+    for (int t = tid; t < m2; t += 1024) {
+        uint64_t key = 0ull;
+        if (t < n_win * kk) {
+            const uint64_t top = mx[t / kk];
+            if (top != 0ull) {
+                const int64_t row = (int64_t)(top & 0xFFFFFFFFull);
+                const int blk = (int)(((row >> 2) % n_waves) >> 2);           // rows are dealt four per wave
+                key = lists[(int64_t)blk * kk + (t % kk)];
+            }
+        }
+        s[t] = key;
+    }
+    __syncthreads();
+    top64_desc(s, m2);
+    const uint64_t kth = s[k - 1];                                            // 0 = fewer than k rows in all (launcher excludes it)
     const float t_lo = order_bits_inverse((uint32_t)(kth >> 32)) - 2.0f * kPrefilterEps;
     const uint32_t thr = order_bits(t_lo);                                    // NaN k-th -> 0xFFFFFFFF: only NaN rows pass
     __syncthreads();
@@ -240,10 +259,10 @@ __global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* _
     }
 }
 
-// Entries a block keeps: at least twice k and at least 16, so that a handful of near-ties inside one block (k = 1: ANY second
+// Entries a block keeps: at least twice k and at least 32, so that a handful of near-ties inside one block (k = 1: ANY second
 // candidate) does not saturate its list; 64 at most (the tournament's width).
 static int prefilter_list_len(int k) {
-    int kk = 2 * k < 16 ? 16 : 2 * k;
+    int kk = 2 * k < 32 ? 32 : 2 * k;
     return kk > kPrefilterMaxK ? kPrefilterMaxK : kk;
 }
 
