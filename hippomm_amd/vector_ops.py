@@ -26,7 +26,9 @@ class FeatureStore:
     """(N,1024) fp32 feature matrix resident in HBM (the ``memory_store`` vision/audio matrix
     of one event, or many events concatenated), plus the scan workspace."""
 
-    def __init__(self, rows: Union[np.ndarray, torch.Tensor], device=None):
+    def __init__(self, rows: Union[np.ndarray, torch.Tensor], device=None, shadow: bool = False):
+        """``shadow=True`` also builds the bf16 shadow (+2048 B per row) and lets ``search`` / ``search_device`` -- and therefore
+        ``top_k_cosine_similarity(q, store, k)`` -- go through it: the same results, bit for bit, for half the bytes streamed."""
         dev = device or _lib.require_gpu()
         if isinstance(rows, np.ndarray):
             self.source_dtype = rows.dtype
@@ -42,6 +44,10 @@ class FeatureStore:
         self.rows = t
         self._ws = None
         self._ws_key = None
+        self.use_shadow = False
+        if shadow and t.shape[0] > 0:
+            self.build_shadow()
+            self.use_shadow = True
 
     def __len__(self):
         return self.rows.shape[0]
@@ -56,6 +62,8 @@ class FeatureStore:
     def search_device(self, query: torch.Tensor, k: int):
         """query: (1024,) fp32 CUDA tensor.  Returns CUDA tensors (idx int64[k'], sims fp32[k'])
         without synchronising (k' = min(k, N))."""
+        if getattr(self, "use_shadow", False):
+            return self.search_prefiltered_device(query, k)
         lib = _lib.load()
         n = len(self)
         if k < 1:

@@ -223,3 +223,19 @@ def test_error_codes_through_the_c_abi():
     assert call(store=rows.data_ptr() + 4) == -1 and b"aligned" in lib.hmm_last_error()
     with pytest.raises(L.HippoMMHipError):
         L.check(call(k=-3), "hmm_cosine_topk_prefilter")
+
+
+def test_feature_store_with_shadow_serves_the_drop_in_call_identically():
+    """FeatureStore(rows, shadow=True): top_k_cosine_similarity(q, store, k) goes through the shadow and returns what it returns
+    without it (indices, similarity bits, dtypes), for float32 and float64 sources and k on both sides of the prefilter's limit."""
+    from hippomm_amd.vector_ops import FeatureStore, top_k_cosine_similarity
+    rng = np.random.default_rng(77)
+    for dtype in (np.float32, np.float64):
+        store = rng.standard_normal((30000, 1024)).astype(np.float32).astype(dtype)
+        q = rng.standard_normal(1024).astype(np.float32)
+        plain, shadowed = FeatureStore(store), FeatureStore(store, shadow=True)
+        assert shadowed.use_shadow and not plain.use_shadow
+        for k in (5, 32, 100):
+            i0, s0 = top_k_cosine_similarity(q, plain, k)
+            i1, s1 = top_k_cosine_similarity(q, shadowed, k)
+            assert i0.tolist() == i1.tolist() and s0.dtype == s1.dtype and s0.tobytes() == s1.tobytes()
