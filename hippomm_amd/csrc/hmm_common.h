@@ -88,22 +88,6 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// ---- sums over the 16 lanes of a DPP row -------------------------------------------------
-// Butterfly over lane bits 0, 1 (quad permutes), 2 (row_half_mirror) and 3 (row_mirror): by the time a mirror is applied the
-// values are uniform over the lanes it also permutes, so every lane ends with  ((v0+v1)+(v2+v3)) + ... , the tree of an
-// xor-butterfly -- the order the folded-LayerNorm chunk statistics are defined by (encoder_ops.h).
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov_f32(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_mov_f32<0xB1>(v);       // quad_perm [1,0,3,2]
-    v += dpp_mov_f32<0x4E>(v);       // quad_perm [2,3,0,1]
-    v += dpp_mov_f32<0x141>(v);      // row_half_mirror
-    v += dpp_mov_f32<0x140>(v);      // row_mirror
-    return v;
-}
-
 // ---- total order used by the scan (see include/hippomm_hip.h) ------------------------------
 // monotone float -> uint32 map; NaN -> 0xFFFFFFFF (ranks first), -0.0 -> +0.0.
 __device__ __forceinline__ uint32_t order_bits(float s) {
