@@ -19,6 +19,7 @@ FEATURE_DIM = 1024
 # after its first call.  The stream and the thread are part of the key: two selections of the same n on different streams or
 # threads never share a workspace.  Only the async entry point uses the cache; the synchronous wrappers own their buffers.
 _BUFFERS = {}
+_BUFFERS_LOCK = threading.Lock()     # lookup / evict / insert as one step; an evicted entry stays alive with whoever holds it
 
 
 def _new_buffers(lib, n, dev):
@@ -50,11 +51,12 @@ def select_key_frames_async(features: torch.Tensor, similarity_threshold: float 
     f = _prepare(features)
     n, dev = f.shape[0], f.device
     key = (dev.index, int(_lib.stream_ptr().value or 0), threading.get_ident(), n)
-    buf = _BUFFERS.get(key)
-    if buf is None:
-        if len(_BUFFERS) >= 16:                             # a handful of sizes recur (frame buffer, per-video totals)
-            _BUFFERS.pop(next(iter(_BUFFERS)))
-        buf = _BUFFERS[key] = _new_buffers(lib, n, dev)
+    with _BUFFERS_LOCK:
+        buf = _BUFFERS.get(key)
+        if buf is None:
+            if len(_BUFFERS) >= 16:                         # a handful of sizes recur (frame buffer, per-video totals)
+                _BUFFERS.pop(next(iter(_BUFFERS)), None)    # the evicted tuple lives on in the caller that still uses it
+            buf = _BUFFERS[key] = _new_buffers(lib, n, dev)
     return _launch(lib, f, similarity_threshold, buf)
 
 

@@ -492,7 +492,8 @@ extern "C" int hmm_cosine_topk_segmented_prefilter(const float* store_dev, const
                                                    void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream) {
     // no tournament beyond 64 keys; and events of a few dozen rows (one 1024-thread workgroup per event: 20 000 events of 50 rows
     // take 0.75 ms this way, 0.79 ms exactly -- nothing to win): the exact path
-    if (k > kPrefilterMaxK || n_rows == 0 || n_rows / n_segments < 128)
+    // (n_segments < 1 goes to the exact entry point too: it reports the argument error -- never a division by zero here)
+    if (k > kPrefilterMaxK || n_rows == 0 || n_segments < 1 || n_rows / n_segments < 128)
         return hmm_cosine_topk_segmented(store_dev, n_rows, dim, query_dev, seg_offsets_dev, n_segments, k, idx_out_dev, sim_out_dev,
                                          n_out_dev, workspace_dev, workspace_bytes, stream);
     HMM_REQUIRE(dim == HMM_FEATURE_DIM, HMM_E_INVALID, "cosine_topk_segmented_prefilter: dim must be %d, got %d", HMM_FEATURE_DIM, dim);

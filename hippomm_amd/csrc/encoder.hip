@@ -30,6 +30,19 @@ HMM_TUNABLE(int, g_enc_split_min_text, 64)  // the same for the text tower (a wa
 HMM_TUNABLE(int, g_enc_two_chain_small_tiles, 64)  // gemm_set_small_tiles of a two-chain forward
 HMM_TUNABLE(int, g_enc_split_min_audio, 12) // the audio tower's smaller kernels overlap from 4 segments on (-7 .. -11 %; tools/split_min_probe.py)
 HMM_TUNABLE(int, g_enc_split_num, 128)   // frames of 256 that go to the first of the two chains
+// Few-row forwards (one frame, one question, one audio segment -- the reference's own call sizes, hippocampal_memory.py:1222,
+// :2173, :2445): fc2 walks K = 4D on few tiles, i.e. a chain of latencies on a mostly idle chip (one frame: 100 tiles of 64 x 64
+// x 80 K-tiles each on 256 CUs, 22 us).  Up to g_enc_splitk_rows token rows per forward it runs split-K (gemm_bf16_splitk: fp32
+// partial slabs, summed in split order by the LayerNorm that follows -- no launch added): one frame 2.45 -> 2.30 ms, one
+// question 1.08 -> 1.00, one segment 0.73 -> 0.70 (profiles/r5_splitk_probe.json).  The split factor is a constant, so a
+// sample gets the same bits at every batch size INSIDE this regime; across the regime boundary the fp32 sum order of fc2
+// differs (embeddings within the stated tolerance; tests/test_gpu_encoder_batch.py has a bitwise test per regime and a
+// tolerance test across).  out-proj (K = D: 16-20 K-tiles) gains nothing from a split (measured) and keeps its epilogue.
+HMM_TUNABLE(int, g_enc_splitk_rows, 700)   // token rows (batch x clips x tokens) up to which a text / audio forward is in the split-K regime (one segment = 687 rows, nine questions = 693); 0 = never
+HMM_TUNABLE(int, g_enc_splitk_rows_vision, 300)   // the same for the vision tower: one frame (two frames: 2.76 -> 2.84 ms with the split)
+HMM_TUNABLE(int, g_enc_splitk_fc2, 2)      // K splits of fc2 (K = 4D), vision and audio towers (four: one frame 2.25 -> 2.27 ms, one segment 0.67 -> 0.69)
+HMM_TUNABLE(int, g_enc_splitk_fc2_text, 4) // the same for the text tower (two / four splits: one question 0.988 / 0.992 ms, two 1.07 / 1.04, four 1.27 / 1.23; unsplit 1.04 / 1.10 / 1.37)
+HMM_TUNABLE(int, g_enc_splitk_out, 1)      // K splits of out-proj (K = D); 1 = the residual epilogue as in every other regime
 
 enum PackKind { PACK_F32, PACK_BF16, PACK_FOLD_CONV3D };
 
@@ -153,9 +166,17 @@ static void plan_params(hmm_encoder* e, std::vector<std::pair<void**, size_t>>& 
     e->arena_bytes = ab.cursor;
 }
 
-struct WsPlan { int n_img, R; size_t off_x, off_a, off_big, off_im2col, off_patch, off_hl, off_hv, off_xc, off_ac, off_qc, off_hc, off_sel, total; };
+struct WsPlan { int n_img, R; size_t off_x, off_a, off_big, off_im2col, off_patch, off_hl, off_hv, off_xc, off_ac, off_qc, off_hc, off_sel, off_part, total; };
 
-static WsPlan ws_plan(const hmm_encoder* e, int batch) {
+// whether a forward of `batch` samples is in the split-K regime (a property of the whole forward, not of a chain)
+static int fc2_splits(const hmm_encoder* e) { return e->tower == HMM_TOWER_TEXT ? g_enc_splitk_fc2_text : g_enc_splitk_fc2; }
+static bool splitk_regime(const hmm_encoder* e, int batch) {
+    const int limit = e->tower == HMM_TOWER_VISION ? g_enc_splitk_rows_vision : g_enc_splitk_rows;
+    return limit > 0 && (int64_t)batch * e->clips * e->T <= limit &&
+           e->D % (64 * g_enc_splitk_out) == 0 && e->mlp % (64 * fc2_splits(e)) == 0;
+}
+
+static WsPlan ws_plan(const hmm_encoder* e, int batch, bool splitk) {
     WsPlan p{};
     p.n_img = batch * e->clips;
     p.R = p.n_img * e->T;
@@ -178,6 +199,9 @@ static WsPlan ws_plan(const hmm_encoder* e, int batch) {
     p.off_qc = cur;  cur = align_up(cur + (size_t)p.n_img * D * 2, 256);
     p.off_hc = cur;  cur = align_up(cur + (size_t)p.n_img * e->mlp * 2, 256);
     p.off_sel = cur; cur = align_up(cur + (size_t)p.n_img * 4, 256);
+    // split-K partial slabs [splits][R][D] fp32 (few-row forwards only)
+    const int max_splits = fc2_splits(e) > g_enc_splitk_out ? fc2_splits(e) : g_enc_splitk_out;
+    p.off_part = cur; cur = align_up(cur + (splitk ? (size_t)max_splits * p.R * D * 4 : 0), 256);
     p.total = cur + 256;
     return p;
 }
@@ -298,9 +322,10 @@ static int split_point(const hmm_encoder* e, int batch) {
 extern "C" size_t hmm_encoder_workspace_bytes(const hmm_encoder* e, int batch) {
     if (!e || batch < 1) return 0;
     const int b0 = split_point(e, batch);
-    const size_t one = ws_plan(e, batch).total;
+    const bool sk = splitk_regime(e, batch);
+    const size_t one = ws_plan(e, batch, sk).total;
     if (b0 == 0) return one;
-    const size_t two = ws_plan(e, b0).total + ws_plan(e, batch - b0).total;
+    const size_t two = ws_plan(e, b0, sk).total + ws_plan(e, batch - b0, sk).total;
     return two > one ? two : one;            // a forward under stream capture runs as one chain (see hmm_encoder_forward)
 }
 
@@ -339,6 +364,8 @@ struct Chain {                 // one (half-)batch travelling through the tower 
     hipStream_t cls_st; hipEvent_t ev_x, ev_cls;      // fork for the cls-row projection of the fused attention path
     int tile;                  // GEMM dispatch of this forward: HMM_GEMM_TILE_AUTO, or AUTO_TILED when the forward is large
     bool fuse;                 // in_proj + attention as one kernel (large enough forwards only, see hmm_encoder_forward)
+    bool splitk;               // few-row forward: out-proj / fc2 as split-K launches reduced by the LayerNorm behind them
+    mutable const float* pending_bias;   // fc2 of the previous block left partial slabs: the next LayerNorm adds them (+ this bias)
 };
 
 #define HMM_TRY(call) do { int _rc = (call); if (_rc != HMM_OK) return _rc; } while (0)
@@ -377,7 +404,12 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
     const BlockW& w = e->blocks[i];
     const bool text = e->tower == HMM_TOWER_TEXT;     // the selected (EOS) row differs per sample: no cls-only shortcut
     const bool fused = e->fused_attention && c.fuse && e->tower == HMM_TOWER_VISION && D == 1280 && e->heads == 16 && T == 257;
-    if (!(i + 1 < e->depth && fused)) HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
+    float* part = reinterpret_cast<float*>(c.ws + p.off_part);
+    const size_t part_stride = (size_t)R * D;
+    if (c.pending_bias) {       // split-K regime (never fused): fc2 of block i - 1 is still in its slabs
+        HMM_TRY(launch_layernorm_reduce_bf16(x, part, part_stride, fc2_splits(e), c.pending_bias, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
+        c.pending_bias = nullptr;
+    } else if (!(i + 1 < e->depth && fused)) HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
     if (i + 1 < e->depth && fused) {
         // in_proj + attention in one kernel per (image, head): the packed qkv matrix never exists in HBM.  The cls rows
         // (one per image: they do not fit the kernel's 256-row tile) go through LayerNorm + a small GEMM of their own, on a
@@ -411,10 +443,20 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
     } else if (i + 1 < e->depth || text) {
         HMM_TRY(gemm_bf16(a, w.qkv_w, w.qkv_b, big, R, 3 * D, D, HMM_EPI_BIAS_BF16, c.tile, st));
         HMM_TRY(attention_bf16(big, a, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st, text));
-        HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, c.tile, st));
-        HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
+        if (c.splitk && g_enc_splitk_out > 1) {
+            HMM_TRY(gemm_bf16_splitk(a, w.out_w, part, R, D, D, g_enc_splitk_out, -1, st));
+            HMM_TRY(launch_layernorm_reduce_bf16(x, part, part_stride, g_enc_splitk_out, w.out_b, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
+        } else {
+            HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, c.tile, st));
+            HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
+        }
         HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, c.tile, st));
-        HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, c.tile, st));
+        if (c.splitk && fc2_splits(e) > 1 && i + 1 < e->depth) {     // the next block's norm_1 reduces (text: the last block has none)
+            HMM_TRY(gemm_bf16_splitk(big, w.fc2_w, part, R, D, e->mlp, fc2_splits(e), -1, st));
+            c.pending_bias = w.fc2_b;
+        } else {
+            HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, c.tile, st));
+        }
     } else {
         // The head reads only token 0 (SelectElement(index=0)), so the LAST block needs K/V for every
         // token but Q, attention output, out-proj and the MLP for the cls row of each image only.
@@ -478,7 +520,9 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
     // The fused in_proj + attention kernel walks one 256 x 256 x D tile per (sample, head): 16 (12) workgroups per frame (clip).
     // Below ~32 frames that leaves most CUs idle behind a long K walk, and the few-row projection GEMM (64 x 64 tiles behind the
     // ring) + the attention kernel are faster (1 frame: 3.85 -> 2.60 ms; tools/fused_small_probe.py).  Same bits either way.
-    const bool fuse = batch * e->clips >= (e->tower == HMM_TOWER_VISION ? g_enc_fused_min_vision : g_enc_fused_min_audio);
+    const bool fuse = e->tower != HMM_TOWER_TEXT &&
+                      batch * e->clips >= (e->tower == HMM_TOWER_VISION ? g_enc_fused_min_vision : g_enc_fused_min_audio);
+    const bool sk = splitk_regime(e, batch) && !fuse;
     Chain chains[2];
     int n_chains = 1;
     int b0 = split_point(e, batch);
@@ -490,13 +534,13 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
         if (cap != hipStreamCaptureStatusNone) b0 = 0;
     }
     if (b0 == 0) {
-        chains[0] = Chain{input_dev, out_dev, ws, ws_plan(e, batch), st, batch, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile, fuse};
+        chains[0] = Chain{input_dev, out_dev, ws, ws_plan(e, batch, sk), st, batch, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile, fuse, sk, nullptr};
     } else {
-        const WsPlan p0 = ws_plan(e, b0);
-        chains[0] = Chain{input_dev, out_dev, ws, p0, st, b0, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile, fuse};
+        const WsPlan p0 = ws_plan(e, b0, sk);
+        chains[0] = Chain{input_dev, out_dev, ws, p0, st, b0, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile, fuse, sk, nullptr};
         chains[1] = Chain{static_cast<const char*>(input_dev) + (size_t)b0 * in_bytes_per_sample, out_dev + (size_t)b0 * HMM_FEATURE_DIM,
-                          ws + p0.total, ws_plan(e, batch - b0), e->side_stream, batch - b0,
-                          e->cls_stream[1], e->ev_x[1], e->ev_cls[1], tile, fuse};
+                          ws + p0.total, ws_plan(e, batch - b0, sk), e->side_stream, batch - b0,
+                          e->cls_stream[1], e->ev_x[1], e->ev_cls[1], tile, fuse, sk, nullptr};
         n_chains = 2;
         HMM_HIP_CHECK(hipEventRecord(e->ev_fork, st));                       // fork
         HMM_HIP_CHECK(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));

@@ -11,6 +11,13 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
 // ping-pong launches pack well (tools/mid_batch_probe.py).  Per host thread; returns the previous value.
 int gemm_set_small_tiles(int tiles);
 
+// Split-K for few-row launches with a long K: `splits` fp32 partial products part[split][M][N] (no bias), added up in split
+// order by launch_layernorm_reduce_bf16 -- the LayerNorm that follows every residual GEMM -- together with the bias and the
+// residual.  tile < 0: by shape among the ring geometries.
+int gemm_bf16_splitk(const bf16_t* A, const bf16_t* W, float* part, int M, int N, int K, int splits, int tile, hipStream_t st);
+int launch_layernorm_reduce_bf16(float* x, const float* part, size_t part_stride, int splits, const float* bias,
+                                 const float* g, const float* b, bf16_t* y, int rows, int D, float eps, hipStream_t st);
+
 int launch_layernorm_bf16(const float* x, size_t in_stride, const float* g, const float* b, bf16_t* y,
                           int rows, int D, float eps, hipStream_t st);
 int launch_assemble_tokens(const float* patches, const float* cls, const float* pos,

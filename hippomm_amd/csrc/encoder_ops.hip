@@ -65,6 +65,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void laye
     }
 }
 
+// The consumer side of a split-K residual GEMM (gemm_bf16_splitk): x[r] = ((p_0[r] + p_1[r] + ... + p_{S-1}[r]) + bias) + x[r]
+// -- the slabs in split order, then the bias, then the residual, the non-split epilogue's (accumulator + bias) + x -- written
+// back to the fp32 stream, and y_bf16[r] = LN(x[r]).  A row's bits depend on S only, not on the launch.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_reduce_bf16_kernel(float* __restrict__ x, const float* __restrict__ part,
+                                                                    size_t part_stride, int splits,
+                                                                    const float* __restrict__ bias,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta,
+                                                                    bf16_t* __restrict__ y, int rows, float eps) {
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* xr = x + (size_t)row * D;
+    const float* pr = part + (size_t)row * D;
+    float4 v[NV], acc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        v[j] = *reinterpret_cast<const float4*>(xr + 4 * (64 * j + lane));
+        acc[j] = *reinterpret_cast<const float4*>(pr + 4 * (64 * j + lane));
+    }
+    for (int s = 1; s < splits; ++s) {
+        const float* ps = pr + (size_t)s * part_stride;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float4 p = *reinterpret_cast<const float4*>(ps + 4 * (64 * j + lane));
+            acc[j].x += p.x; acc[j].y += p.y; acc[j].z += p.z; acc[j].w += p.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + 4 * (64 * j + lane));
+        v[j] = make_float4((acc[j].x + b.x) + v[j].x, (acc[j].y + b.y) + v[j].y, (acc[j].z + b.z) + v[j].z, (acc[j].w + b.w) + v[j].w);
+        *reinterpret_cast<float4*>(xr + 4 * (64 * j + lane)) = v[j];
+    }
+    row_layernorm<NV>(v, gamma, beta, eps, lane);
+    bf16_t* dst = y + (size_t)row * D;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        bf16x4 o = {(bf16_t)v[j].x, (bf16_t)v[j].y, (bf16_t)v[j].z, (bf16_t)v[j].w};
+        *reinterpret_cast<bf16x4*>(dst + 4 * (64 * j + lane)) = o;
+    }
+}
+
 // x[b*T + t] = pre_ln( (t == 0 ? cls : stem_ln(patch[b*P + t-1])) + pos[t] )
 template <int NV>
 __global__ __launch_bounds__(256) void assemble_tokens_kernel(
@@ -273,6 +318,19 @@ int launch_layernorm_bf16(const float* x, size_t in_stride, const float* g, cons
     return HMM_OK;
 }
 
+int launch_layernorm_reduce_bf16(float* x, const float* part, size_t part_stride, int splits, const float* bias,
+                                 const float* g, const float* b, bf16_t* y, int rows, int D, float eps, hipStream_t st) {
+    HMM_REQUIRE(D == 768 || D == 1024 || D == 1280, HMM_E_INVALID, "layernorm_reduce: D must be 768, 1024 or 1280, got %d", D);
+    HMM_REQUIRE(splits >= 1 && splits <= 8, HMM_E_INVALID, "layernorm_reduce: splits=%d", splits);
+    if (rows <= 0) return HMM_OK;
+    const int blocks = (rows + 3) / 4;
+    if (D == 768)       layernorm_reduce_bf16_kernel<3><<<blocks, 256, 0, st>>>(x, part, part_stride, splits, bias, g, b, y, rows, eps);
+    else if (D == 1024) layernorm_reduce_bf16_kernel<4><<<blocks, 256, 0, st>>>(x, part, part_stride, splits, bias, g, b, y, rows, eps);
+    else                layernorm_reduce_bf16_kernel<5><<<blocks, 256, 0, st>>>(x, part, part_stride, splits, bias, g, b, y, rows, eps);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+
 int launch_assemble_tokens(const float* patches, const float* cls, const float* pos,
                            const float* stem_g, const float* stem_b, float stem_eps,
                            const float* pre_g, const float* pre_b, float pre_eps,
@@ -354,4 +412,12 @@ extern "C" int hmm_op_layernorm_bf16(const float* x_dev, const float* gamma_dev,
     HMM_REQUIRE(x_dev && gamma_dev && beta_dev && y_dev, HMM_E_INVALID, "layernorm: null pointer");
     return launch_layernorm_bf16(x_dev, (size_t)D, gamma_dev, beta_dev, reinterpret_cast<bf16_t*>(y_dev), rows, D, eps,
                                  static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hmm_op_layernorm_reduce_bf16(float* x_dev, const float* part_dev, int splits, const float* bias_dev,
+                                            const float* gamma_dev, const float* beta_dev, uint16_t* y_dev, int rows, int D,
+                                            float eps, hmm_stream_t stream) {
+    HMM_REQUIRE(x_dev && part_dev && bias_dev && gamma_dev && beta_dev && y_dev, HMM_E_INVALID, "layernorm_reduce: null pointer");
+    return launch_layernorm_reduce_bf16(x_dev, part_dev, (size_t)rows * D, splits, bias_dev, gamma_dev, beta_dev,
+                                        reinterpret_cast<bf16_t*>(y_dev), rows, D, eps, static_cast<hipStream_t>(stream));
 }

@@ -114,7 +114,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float*
 template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2, int KSUB = 1>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    void* __restrict__ Cout, int M, int N, int K, int tiles_n) {
+    void* __restrict__ Cout, int M, int N, int K, int tiles_n, int tiles_m, int col_major, int k_len) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
@@ -127,11 +127,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    // bijective XCD-aware remap of the linear block id
+    // bijective XCD-aware remap of the linear block id: XCD x (= blockIdx % 8) takes a contiguous run of the work list.
+    // The list is [K split][tile]; tiles row-major (a row tile's column tiles are neighbours: an XCD shares A panels) or
+    // column-major (a column tile's row tiles are neighbours: an XCD shares W panels, and with few row tiles every weight
+    // byte leaves HBM / the Infinity Cache once instead of once per row tile -- see launch_gemm).
     const int nb = gridDim.x, bid = blockIdx.x;
     const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int m0 = (swz / tiles_n) * BM, n0 = (swz % tiles_n) * BN;
+    const int tiles = tiles_m * tiles_n;
+    const int split = swz / tiles, tl = swz - split * tiles;      // split > 0 only in a split-K launch (grid = splits x tiles)
+    const int m0 = (col_major ? tl % tiles_m : tl / tiles_n) * BM, n0 = (col_major ? tl / tiles_m : tl % tiles_n) * BN;
+    A += (size_t)split * k_len;                                   // this workgroup's K range: columns [split k_len, + k_len)
+    W += (size_t)split * k_len;
+    if (nb > tiles) Cout = static_cast<float*>(Cout) + (size_t)split * M * N;   // split-K: fp32 partial slab of this split
 
     // per-lane staging sources (pre-swizzled), one per 1-KiB wave-instruction
     const bf16_t* a_src[A_PER_WAVE];
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int KT = K / (64 * KSUB);                      // ring steps (groups of KSUB K-tiles)
+    const int KT = k_len / (64 * KSUB);                  // ring steps (groups of KSUB K-tiles)
     // All fragment reads of the K-tile first, then the MFMAs in K order behind COUNTED waits: the second half's reads are in
     // flight under the first half's MFMAs (one exposed LDS latency per K-tile instead of two; with one wave per SIMD nothing else
     // hides it).  The reads are inline assembly because the compiler waits for lgkmcnt(0) before the first MFMA however the
@@ -608,16 +616,32 @@ static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
     return HMM_OK;
 }
 
+// Tile order of the tiled kernels (which workgroup computes a tile does not change the tile: same bits).  With fewer row
+// tiles than column tiles -- few-row launches: one frame's qkv GEMM is 5 x 60 tiles of 64 x 64 -- the row-major list hands
+// every XCD a run of column tiles of ONE row tile, so each W panel is pulled through the fabric by five different XCDs
+// (49 MB for 9.8 MB of weights) while the tiny A panels are what gets shared; column-major hands an XCD whole columns.
+// Built and measured in round 5 (profiles/r5_splitk_probe.json, r5_splitk_forward.json): alone with cold weights one
+// frame's qkv / fc1 13.8 -> 13.3 / 15.3 -> 14.3 us, but IN the forwards 0 ... +4 % (one / two / four questions +1.5 / +2.8 /
+// +4.3 %, one frame +0.9 %): the fabric is not what these launches wait for.  Row-major stays; 1 = column-major in the
+// probe build only.
+HMM_TUNABLE(int, g_gemm_col_major, 0)
+static thread_local int t_gemm_tail_launch = 0;       // the peeled tail of a big launch keeps the row-major list (set by gemm_bf16)
+static thread_local int t_gemm_splits = 1;            // > 1: the next launch_gemm is a split-K launch (set by gemm_bf16_splitk)
+
 template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2, int KSUB = 1>
 static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                        hipStream_t st) {
     constexpr int LDS = STAGES * KSUB * (BM + BN) * 128;
     static_assert(LDS <= 160 * 1024, "ring of the tiled GEMM: LDS");
-    HMM_REQUIRE((K / 64) % KSUB == 0, HMM_E_INVALID, "gemm: K = %d is not a multiple of %d (deep-K ring)", K, 64 * KSUB);
+    const int splits = t_gemm_splits;
+    HMM_REQUIRE(K % splits == 0 && ((K / splits) / 64) % KSUB == 0 && (K / splits) % 64 == 0, HMM_E_INVALID,
+                "gemm: K = %d / %d splits is not a multiple of %d", K, splits, 64 * KSUB);
+    HMM_REQUIRE(splits == 1 || (EPI == HMM_EPI_F32 && bias == nullptr), HMM_E_INVALID, "gemm: split-K writes fp32 partials only");
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, STAGES, KSUB>;
     HMM_ENSURE_DYN_LDS(kern, LDS);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
-    kern<<<tiles_m * tiles_n, WM * WN * 64, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n);
+    const int col_major = g_gemm_col_major > 0 && !t_gemm_tail_launch && 2 * tiles_m <= tiles_n;
+    kern<<<tiles_m * tiles_n * splits, WM * WN * 64, LDS, st>>>(A, W, bias, C, M, N, K, tiles_n, tiles_m, col_major, K / splits);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
@@ -837,8 +861,11 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         if (rc != HMM_OK) return rc;
         if (g_gemm_skip_tail) return rc;                         // probe build only (timing upper bound; results are wrong)
         const bool c_bf16 = epi == HMM_EPI_BIAS_BF16 || epi == HMM_EPI_BIAS_GELU_BF16;
-        return launch_gemm_small_epi(A + (size_t)m_main * K, W, bias,
-                                     static_cast<char*>(C) + (size_t)m_main * N * (c_bf16 ? 2 : 4), M - m_main, N, K, epi, st, true);
+        t_gemm_tail_launch = 1;
+        rc = launch_gemm_small_epi(A + (size_t)m_main * K, W, bias,
+                                   static_cast<char*>(C) + (size_t)m_main * N * (c_bf16 ? 2 : 4), M - m_main, N, K, epi, st, true);
+        t_gemm_tail_launch = 0;
+        return rc;
     }
     switch (tile) {
         case HMM_GEMM_TILE_SLIVER:     return launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, st);
@@ -857,9 +884,55 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
     return HMM_E_INVALID;
 }
 
+// Deterministic split-K for launches of few rows x a long K (out-proj / fc2 of one frame, one question, one segment): the
+// K walk is a chain of latencies -- one frame's fc2 is 100 tiles of 64 x 64 walking 80 K-tiles each on 256 CUs -- so `splits`
+// workgroups per tile walk K / splits each and write their fp32 partial products to slab[split][M][N]; the consumer (the
+// LayerNorm behind every residual GEMM: launch_layernorm_reduce_bf16) adds the slabs in split order, the bias and the
+// residual, so no launch is added and an element's bits depend on (N, K, splits) only -- not on M, the tile geometry or timing.
+HMM_TUNABLE(int, g_gemm_splitk_tile, -1)     // probe build: force a ring geometry for the split launches
+int gemm_bf16_splitk(const bf16_t* A, const bf16_t* W, float* part, int M, int N, int K, int splits, int tile, hipStream_t st) {
+    HMM_REQUIRE(A && W && part, HMM_E_INVALID, "gemm_splitk: null pointer");
+    HMM_REQUIRE(M >= 1 && N >= 128 && N % 128 == 0 && splits >= 1 && splits <= 8 && K % (64 * splits) == 0, HMM_E_INVALID,
+                "gemm_splitk: unsupported shape M=%d N=%d K=%d splits=%d", M, N, K, splits);
+    if (g_gemm_splitk_tile >= 0) tile = g_gemm_splitk_tile;
+    const int k_len = K / splits;
+    if (tile < 0) {
+        // by the number of 64 x 64 workgroups (profiles/r5_splitk_probe.json, cold weights): under half a chip of them, 32 x 32
+        // tiles put four times the workgroups to work (one question's fc2: 11.2 vs 14.3 us); up to one per CU, 64 x 64 tiles with
+        // two K-tiles per ring stage (one frame's fc2: 12.6 us, 22 unsplit); beyond that the plain rings
+        const long w64 = (long)((M + 63) / 64) * (N / 64) * splits;
+        const bool k2 = k_len % 128 == 0;
+        if (w64 < 128) tile = k2 ? HMM_GEMM_TILE_32x32_RING_K2 : HMM_GEMM_TILE_32x32_RING;
+        else if (w64 <= 256) tile = k2 ? HMM_GEMM_TILE_64x64_RING_K2 : HMM_GEMM_TILE_64x64_RING;
+        else if (w64 <= 1024) tile = HMM_GEMM_TILE_64x64_RING;
+        else tile = HMM_GEMM_TILE_128x128_RING;
+    }
+    t_gemm_splits = splits;
+    int rc;
+    switch (tile) {
+        case HMM_GEMM_TILE_128x128_RING:  rc = launch_gemm<128, 128, 2, 2, HMM_EPI_F32, 4>(A, W, nullptr, part, M, N, K, st); break;
+        case HMM_GEMM_TILE_64x64_RING:    rc = launch_gemm<64, 64, 2, 2, HMM_EPI_F32, 4>(A, W, nullptr, part, M, N, K, st); break;
+        case HMM_GEMM_TILE_32x32_RING:    rc = launch_gemm<32, 32, 2, 2, HMM_EPI_F32, 4>(A, W, nullptr, part, M, N, K, st); break;
+        case HMM_GEMM_TILE_64x64_RING_K2: rc = launch_gemm<64, 64, 2, 2, HMM_EPI_F32, 3, 2>(A, W, nullptr, part, M, N, K, st); break;
+        case HMM_GEMM_TILE_32x32_RING_K2: rc = launch_gemm<32, 32, 2, 2, HMM_EPI_F32, 4, 2>(A, W, nullptr, part, M, N, K, st); break;
+        case HMM_GEMM_TILE_32x32_RING_K4: rc = launch_gemm<32, 32, 2, 2, HMM_EPI_F32, 4, 4>(A, W, nullptr, part, M, N, K, st); break;
+        default:
+            set_error("gemm_splitk: tile geometry %d has no split-K launch", tile);
+            rc = HMM_E_INVALID;
+    }
+    t_gemm_splits = 1;
+    return rc;
+}
+
 }  // namespace hmm
 
 using namespace hmm;
+
+extern "C" int hmm_op_gemm_bf16_splitk(const uint16_t* a_dev, const uint16_t* w_dev, float* part_dev, int M, int N, int K,
+                                       int splits, int tile, hmm_stream_t stream) {
+    return gemm_bf16_splitk(reinterpret_cast<const bf16_t*>(a_dev), reinterpret_cast<const bf16_t*>(w_dev), part_dev, M, N, K,
+                            splits, tile, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int hmm_op_gemm_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev, void* c_dev,
                                 int M, int N, int K, int epilogue, hmm_stream_t stream) {

@@ -11,7 +11,9 @@ call, which is correct but PCIe-bound.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import weakref
+import zlib
 from typing import List, Tuple, Union
 
 import numpy as np
@@ -28,7 +30,8 @@ class FeatureStore:
 
     def __init__(self, rows: Union[np.ndarray, torch.Tensor], device=None, shadow: bool = False):
         """``shadow=True`` also builds the bf16 shadow (+2048 B per row) and lets ``search`` / ``search_device`` -- and therefore
-        ``top_k_cosine_similarity(q, store, k)`` -- go through it: the same results, bit for bit, for half the bytes streamed."""
+        ``top_k_cosine_similarity(q, store, k)`` -- go through it: the same results, bit for bit, for half the bytes streamed.
+        The rows must stay unchanged while a shadow exists (see ``build_shadow``)."""
         dev = device or _lib.require_gpu()
         if isinstance(rows, np.ndarray):
             self.source_dtype = rows.dtype
@@ -79,15 +82,31 @@ class FeatureStore:
                    "hmm_cosine_topk")
         return idx, sims
 
-    def build_shadow(self):
+    def build_shadow(self, force: bool = False):
         """Build the bf16 shadow of the store (2048 B per row beside the 4096-B fp32 rows; hmm_shadow_store_build) that
-        ``search_prefiltered_device`` streams.  Idempotent."""
-        if getattr(self, "_shadow", None) is None:
+        ``search_prefiltered_device`` streams.  Idempotent unless ``force``.
+
+        The shadow is a SNAPSHOT: ``self.rows`` must not change while it exists (``FeatureStore`` / ``from_device_rows`` alias
+        a caller's fp32 CUDA tensor without copying).  An in-place update made through torch bumps the tensor's version
+        counter, which the searches check: the shadow is then rebuilt before it is used.  Writes that bypass torch (a raw
+        kernel on ``rows.data_ptr()``) need ``invalidate_shadow()`` or ``build_shadow(force=True)``.  The build is enqueued
+        on the current stream; searches on another stream must be ordered after it by the caller."""
+        version = getattr(self.rows, "_version", 0)
+        if force or getattr(self, "_shadow", None) is None or getattr(self, "_shadow_version", version) != version:
             lib = _lib.load()
             n = len(self)
-            self._shadow = torch.empty(lib.hmm_shadow_store_bytes(n), dtype=torch.uint8, device=self.rows.device)
+            need = lib.hmm_shadow_store_bytes(n)
+            if getattr(self, "_shadow", None) is None or self._shadow.numel() != need:
+                self._shadow = torch.empty(need, dtype=torch.uint8, device=self.rows.device)
             _lib.check(lib.hmm_shadow_store_build(self.rows.data_ptr(), n, FEATURE_DIM, self._shadow.data_ptr(),
                                                   self._shadow.numel(), _lib.stream_ptr()), "hmm_shadow_store_build")
+            self._shadow_version = version
+        return self
+
+    def invalidate_shadow(self):
+        """Forget the bf16 shadow (after the fp32 rows were modified behind torch's back); the next prefiltered search
+        rebuilds it."""
+        self._shadow = None
         return self
 
     def search_prefiltered_device(self, query: torch.Tensor, k: int, stats: torch.Tensor = None):
@@ -206,53 +225,70 @@ def merge_keys_device(keys: torch.Tensor, row_offsets: torch.Tensor, k: int):
 # ---- optional residency for the UNCHANGED reference loop ----------------------------------------------------------------------
 # The reference calls top_k_cosine_similarity(query, event.features['vision'], k=5) once per event and question with the event's
 # host array (hippocampal_memory.py:3143-3153): as a drop-in that is a host-side fp32 conversion plus an upload per call (~1 ms
-# per event).  With the cache enabled a numpy store seen before is served from its resident FeatureStore.  OFF by default: an
-# array modified IN PLACE between two calls is only noticed through a sampled fingerprint (64 rows x 16 columns, the buffer
-# address, shape, dtype and strides), which the reference's code never does to event features but a caller might.
+# per event).  With the cache enabled a numpy store seen before is served from its resident FeatureStore.  OFF by default.
+# What it assumes: an array modified IN PLACE between two calls is noticed through a fingerprint of its contents -- the CRC-32
+# of EVERY byte for arrays up to 64 MB (the reference's per-event matrices are 0.1-3 MB: ~1 ms per MB on one host core, still
+# several times cheaper than the conversion + upload it saves), and only a 64-row x 16-column sample (plus buffer address,
+# shape, dtype, strides) above that, where a write to an unsampled element returns results from the stale HBM copy.
 _STORE_CACHE = None
+FULL_FINGERPRINT_BYTES = 64 << 20
 
 
 class _StoreCache:
-    def __init__(self, max_bytes: int):
+    def __init__(self, max_bytes: int, full_fingerprint_bytes: int = FULL_FINGERPRINT_BYTES):
         self.max_bytes, self.bytes, self.entries, self.hits, self.misses = int(max_bytes), 0, {}, 0, 0
+        self.full_fingerprint_bytes = int(full_fingerprint_bytes)
+        self._lock = threading.RLock()           # entries / bytes are also touched by weak-reference callbacks (any thread)
 
-    @staticmethod
-    def fingerprint(b: np.ndarray):
+    def fingerprint(self, b: np.ndarray):
+        head = (b.ctypes.data, b.shape, b.dtype.str, b.strides)
+        if b.nbytes <= self.full_fingerprint_bytes:
+            flat = b if b.flags.c_contiguous else np.ascontiguousarray(b)
+            return head + ("crc32", zlib.crc32(memoryview(flat).cast("B")))
         rows = b.reshape(1, -1) if b.ndim == 1 else b
         pick = np.unique(np.linspace(0, rows.shape[0] - 1, num=min(rows.shape[0], 64)).astype(np.int64))
-        return (b.ctypes.data, b.shape, b.dtype.str, b.strides, hash(np.ascontiguousarray(rows[pick][:, ::64]).tobytes()))
+        return head + ("sampled", hash(np.ascontiguousarray(rows[pick][:, ::64]).tobytes()))
 
     def get(self, b: np.ndarray) -> "FeatureStore":
         key, fp = id(b), self.fingerprint(b)
-        ent = self.entries.get(key)
-        if ent is not None and ent[0]() is b and ent[2] == fp:
-            self.hits += 1
-            self.entries[key] = self.entries.pop(key)            # most recently used last
-            return ent[1]
-        if ent is not None:
-            self._drop(key)
-        self.misses += 1
+        with self._lock:
+            ent = self.entries.get(key)
+            if ent is not None and ent[0]() is b and ent[2] == fp:
+                self.hits += 1
+                self.entries[key] = self.entries.pop(key)            # most recently used last
+                return ent[1]
+            if ent is not None:
+                self._drop(key)
+            self.misses += 1
         store = FeatureStore(b)
         size = store.rows.numel() * 4
-        while self.entries and self.bytes + size > self.max_bytes:
-            self._drop(next(iter(self.entries)))
-        # the weak reference's callback releases the HBM copy when the host array dies
-        self.entries[key] = (weakref.ref(b, lambda _r, k=key: self._drop(k)), store, fp, size)
-        self.bytes += size
+        with self._lock:
+            while self.entries and self.bytes + size > self.max_bytes:
+                self._drop(next(iter(self.entries)))
+            # the weak reference's callback releases the HBM copy when the host array dies
+            self.entries[key] = (weakref.ref(b, lambda _r, k=key: self._drop(k)), store, fp, size)
+            self.bytes += size
         return store
 
     def _drop(self, key):
-        ent = self.entries.pop(key, None)
-        if ent is not None:
-            self.bytes -= ent[3]
+        with self._lock:
+            ent = self.entries.pop(key, None)
+            if ent is not None:
+                self.bytes -= ent[3]
 
 
-def enable_store_cache(max_bytes: int = 8 << 30):
+def enable_store_cache(max_bytes: int = 8 << 30, full_fingerprint_bytes: int = FULL_FINGERPRINT_BYTES):
     """Keep the feature matrices that ``top_k_cosine_similarity`` receives as numpy arrays resident in HBM between calls (up to
     ``max_bytes`` of fp32 rows, least recently used first out): the reference's per-event loop then runs unchanged at the
-    resident-store rate.  See the note above ``_STORE_CACHE`` for what it assumes."""
+    resident-store rate.
+
+    Staleness: every call fingerprints the host array.  Arrays of at most ``full_fingerprint_bytes`` (default 64 MB; the
+    reference's per-event matrices are 0.1-3 MB) are hashed WHOLE (CRC-32 of every byte), so any in-place edit is a miss and
+    the array is uploaded again.  Larger arrays are fingerprinted by a 64-row x 16-column sample plus address / shape / dtype /
+    strides only: an in-place write to an unsampled element of such an array is NOT noticed and the answer comes from the
+    stale resident copy -- wrap big stores in a ``FeatureStore`` yourself instead of relying on the cache."""
     global _STORE_CACHE
-    _STORE_CACHE = _StoreCache(max_bytes)
+    _STORE_CACHE = _StoreCache(max_bytes, full_fingerprint_bytes)
     return _STORE_CACHE
 
 

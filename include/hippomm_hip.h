@@ -269,7 +269,19 @@ int hmm_op_gemm_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* 
 #define HMM_GEMM_TILE_32x32_RING_K4 10  /* 32x32 tiles, 4 K-tiles per stage, 4 stages (128 KiB): few rows x a long K (one question's fc2); K % 256 == 0 */
 int hmm_op_gemm_bf16_tile(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
                           void* c_dev, int M, int N, int K, int epilogue, int tile, hmm_stream_t stream);
-/* y_bf16[rows, D] = LayerNorm(x_f32[rows, D]) * gamma + beta ; D in {768, 1280} */
+/* Deterministic split-K (few-row forwards: one frame, one question, one audio segment; hippocampal_memory.py:1180, :1222,
+ * :2173 call the encoder with such batches): part_dev[s][M][N] fp32 = A[:, s K/splits : (s+1) K/splits] W[:, same]^T for
+ * s < splits, no bias; K % (64 splits) == 0; tile = one of the *_RING geometries or < 0 for a choice by shape.  An element's
+ * bits depend on (K, splits) only -- every geometry walks a split's K range in the same order. */
+int hmm_op_gemm_bf16_splitk(const uint16_t* a_dev, const uint16_t* w_dev, float* part_dev, int M, int N, int K,
+                            int splits, int tile, hmm_stream_t stream);
+/* The consumer of those slabs: x_f32[rows, D] = ((part[0] + part[1] + ... + part[splits-1]) + bias) + x (in place, the
+ * slabs in split order) and y_bf16 = LayerNorm(x) * gamma + beta -- the residual epilogue of the GEMM and the LayerNorm
+ * behind it in one launch.  part_dev [splits][rows][D] fp32; D in {768, 1024, 1280}. */
+int hmm_op_layernorm_reduce_bf16(float* x_dev, const float* part_dev, int splits, const float* bias_dev,
+                                 const float* gamma_dev, const float* beta_dev, uint16_t* y_dev, int rows, int D,
+                                 float eps, hmm_stream_t stream);
+/* y_bf16[rows, D] = LayerNorm(x_f32[rows, D]) * gamma + beta ; D in {768, 1024, 1280} */
 int hmm_op_layernorm_bf16(const float* x_dev, const float* gamma_dev, const float* beta_dev,
                           uint16_t* y_dev, int rows, int D, float eps, hmm_stream_t stream);
 /* Multi-head self-attention core on packed qkv (rows = batch*tokens, 3*D columns ordered

@@ -176,38 +176,61 @@ def test_full_depth_audio_batch128_and_text_batch96_bitwise_batch_invariance():
            what="text full depth B=96")
 
 
-def test_one_sample_at_a_time_equals_the_batch_bitwise():
-    """The reference embeds one question, one query frame, one audio segment at a time.  Those forwards take other kernels than
-    a batch does -- the sliver GEMM and 64x64 tiles behind the LDS-DMA ring instead of the ping-pong kernel, projection GEMM +
-    attention kernel instead of the fused kernel, one chain instead of two -- and must give the same bits as the same sample
-    inside a batch (depth 3; every dispatch boundary is crossed between batch sizes 1, 3 and the whole batch)."""
+def _towers_for_regimes():
     from hippomm_amd.encoder import HipTower
     spec = ib.reduced(ib.VISION_HUGE, 3)
-    tower = HipTower("vision", ib.synthetic_state(spec, seed=31, init="rich"), depth=3)
-    x = _frames(40, seed=12)
-    whole = tower(x)                                           # two chains of 20, fused attention
-    assert torch.equal(whole, tower(x, max_batch=1))
-    assert torch.equal(whole, tower(x, max_batch=3))
-    assert torch.equal(whole[:17], tower(x[:17]))              # 17 frames: two chains, projection GEMM + attention kernel
-    del tower
+    yield "vision", HipTower("vision", ib.synthetic_state(spec, seed=31, init="rich"), depth=3), _frames(40, seed=12), 1, 2
     spec = ib.reduced(ib.AUDIO_HUGE, 3)
-    tower = HipTower("audio", ib.synthetic_state(spec, seed=32, init="rich"), depth=3)
     mels = torch.randn(9, 3, 1, 128, 204, generator=torch.Generator().manual_seed(13))
-    whole = tower(mels)
-    assert torch.equal(whole, tower(mels, max_batch=1))
-    assert torch.equal(whole, tower(mels, max_batch=2))
-    del tower
+    yield "audio", HipTower("audio", ib.synthetic_state(spec, seed=32, init="rich"), depth=3), mels, 1, 2
     spec = ib.reduced(ib.TEXT_HUGE, 3)
-    tower = HipTower("text", ib.synthetic_state(spec, seed=33, init="rich"), depth=3)
     tok = torch.randint(1, 49000, (70, 77), generator=torch.Generator().manual_seed(14))
     for b in range(70):
         n = 1 + (b * 11) % 76
         tok[b, n] = 49407
         tok[b, n + 1:] = 0
-    whole = tower(tok)                                         # two chains of 35
-    assert torch.equal(whole, tower(tok, max_batch=1))
-    assert torch.equal(whole, tower(tok, max_batch=4))
-    assert torch.equal(whole[:20], tower(tok[:20]))
+    yield "text", HipTower("text", ib.synthetic_state(spec, seed=33, init="rich"), depth=3), tok, 9, 10
+
+
+def test_a_sample_gets_the_same_bits_at_every_batch_size_within_a_regime():
+    """The reference embeds one question, one query frame, one audio segment at a time (hippocampal_memory.py:1222, :2173, :2445)
+    and buffers of up to 32 frames (:1328).  Two regimes (hmm_encoder_forward): few-row forwards -- one frame, one audio segment, up to
+    nine questions (300 / 700 token rows) -- run fc2 as a deterministic split-K launch reduced inside the next
+    LayerNorm; larger forwards keep the residual epilogue.  INSIDE a regime a sample's embedding does not depend on the batch
+    it rides in, although the kernels change with the batch size (sliver GEMM / 32x32, 64x64, 128x128 rings / ping-pong,
+    projection GEMM + attention kernel / fused kernel, one chain / two): bitwise, depth 3, every dispatch boundary crossed."""
+    for name, tower, x, small_max, large_min in _towers_for_regimes():
+        # few-row regime: one sample at a time == the largest batches that are still inside it
+        one = tower(x, max_batch=1)
+        if small_max > 1:
+            assert torch.equal(one, tower(x, max_batch=small_max)), name
+            assert torch.equal(one, tower(x, max_batch=max(2, small_max // 2))), name
+        assert torch.equal(one, tower(x, max_batch=1)), name                  # run to run
+        # large regime: the whole batch (two chains; vision: fused attention) == the smallest batches outside the few-row regime
+        whole = tower(x)
+        m = len(x) // large_min * large_min                                   # no short last chunk: it would be a few-row forward
+        assert torch.equal(whole[:m], tower(x[:m], max_batch=large_min)), name
+        n = {"vision": 17, "audio": 5, "text": 20}[name]                      # vision: two chains, projection GEMM + attention kernel
+        assert torch.equal(whole[:n], tower(x[:n])), name
+        del tower
+
+
+def test_regimes_agree_within_the_stated_tolerance():
+    """Across the regime boundary only the fp32 summation order of fc2 differs (two partial sums of K/2 products each, added in
+    split order, instead of one walk over K): the embeddings agree to the tolerance every tower test states against the fp32
+    oracle (cos >= 1 - 5e-5), and both regimes are oracle-checked themselves."""
+    fwd = {"vision": ib.vision_forward, "audio": ib.audio_forward, "text": ib.text_forward}
+    scale = {"vision": 1.0, "audio": 20.0, "text": 1.0 / 0.07}
+    for name, tower, x, small_max, large_min in _towers_for_regimes():
+        one, whole = tower(x, max_batch=1), tower(x)
+        assert not torch.equal(one, whole), f"{name}: the few-row regime was not taken"
+        _check(one, whole, scale=scale[name], what=f"{name} depth3 few-row regime vs large regime")
+        spec = ib.reduced({"vision": ib.VISION_HUGE, "audio": ib.AUDIO_HUGE, "text": ib.TEXT_HUGE}[name], 3)
+        st = ib.synthetic_state(spec, seed={"vision": 31, "audio": 32, "text": 33}[name], init="rich")
+        want = fwd[name](x[:4], st, spec)
+        _check(one[:4], want, scale=scale[name], what=f"{name} depth3 few-row regime vs oracle")
+        _check(whole[:4], want, scale=scale[name], what=f"{name} depth3 large regime vs oracle")
+        del tower
 
 
 @pytest.mark.parametrize("batch,streams", [(6, 2), (70, 1), (70, 2)])

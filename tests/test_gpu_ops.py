@@ -236,6 +236,77 @@ def test_layernorm(rows, D):
     _close_bf16(y, want, extra_atol=1e-5)
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(77, 1024, 4096, 2), (257, 1280, 5120, 2), (514, 1280, 5120, 2), (687, 768, 3072, 2),
+                                           (77, 1024, 4096, 4), (300, 1280, 1280, 2), (40, 768, 3072, 8), (1030, 1280, 5120, 4)])
+def test_gemm_split_k_partials_and_the_layernorm_that_reduces_them(M, N, K, splits):
+    """Few-row forwards run fc2 as a split-K launch: slab s = A[:, K_s] W[:, K_s]^T in fp32 (no bias), and the LayerNorm behind the
+    GEMM adds the slabs in split order, the bias and the residual.  Checked: every slab against a torch fp32 product of the same
+    bf16 operands; the slabs bitwise equal across every ring geometry and the choice by shape (an element's bits depend on
+    (K, splits) only); x and LayerNorm(x) against the torch composition; rows past M untouched; and that with splits = 1 the
+    pair is bit-identical to the residual epilogue followed by the plain LayerNorm kernel."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(M + N + K + splits)
+    a = _bf16(torch.randn(M, K, generator=g))
+    w = _bf16(torch.randn(N, K, generator=g) * 0.05)
+    bias, gamma, beta = torch.randn(N, generator=g), 1 + 0.2 * torch.randn(N, generator=g), 0.3 * torch.randn(N, generator=g)
+    x0 = torch.randn(M, N, generator=g) * 2
+    ad, wd, bd, gd, btd = a.cuda(), w.cuda(), bias.cuda(), gamma.cuda(), beta.cuda()
+    kl = K // splits
+    want_parts = torch.stack([a[:, s * kl:(s + 1) * kl].float() @ w[:, s * kl:(s + 1) * kl].float().T for s in range(splits)])
+    slabs = {}
+    for tile in (-1, 6, 7, 8, 9, 10, 11):
+        if tile in (9, 11) and kl % 128 or tile == 10 and kl % 256:
+            continue
+        part = torch.full((splits * M + 2, N), float("nan"), device="cuda")
+        L.check(lib.hmm_op_gemm_bf16_splitk(ad.data_ptr(), wd.data_ptr(), part.data_ptr(), M, N, K, splits, tile, L.stream_ptr()), "splitk")
+        assert torch.isnan(part[splits * M:]).all(), "rows past the last slab were written"
+        slabs[tile] = part[:splits * M].reshape(splits, M, N)
+    ref = slabs[-1]
+    err = (ref.cpu() - want_parts).abs().max().item()
+    assert err <= 2e-4 * max(1.0, want_parts.abs().max().item()), err
+    for tile, p in slabs.items():
+        assert torch.equal(p, ref), f"split-K slabs of tile geometry {tile} differ from the default choice"
+    # the reducing LayerNorm
+    x = torch.cat([x0, torch.full((1, N), float("nan"))]).cuda()
+    y = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_layernorm_reduce_bf16(x.data_ptr(), ref.data_ptr(), splits, bd.data_ptr(), gd.data_ptr(), btd.data_ptr(),
+                                             y.data_ptr(), M, N, 1e-6, L.stream_ptr()), "layernorm_reduce")
+    acc = ref[0].clone()
+    for s in range(1, splits):
+        acc += ref[s]
+    want_x = (acc + bd) + x0.cuda()                    # the kernel's own order: slabs, bias, residual
+    assert torch.equal(x[:M], want_x) and torch.isnan(x[M:]).all()
+    _close_bf16(y[:M], F.layer_norm(want_x.cpu(), (N,), gamma, beta, 1e-6), extra_atol=1e-5)
+    assert torch.isnan(y[M:].float()).all()
+    full = a.float() @ w.float().T + bias + x0        # and the value of the whole thing
+    assert (x[:M].cpu() - full).abs().max().item() <= 3e-4 * max(1.0, full.abs().max().item())
+    # one split == residual epilogue + LayerNorm kernel, bit for bit
+    part1 = torch.empty(M, N, device="cuda")
+    L.check(lib.hmm_op_gemm_bf16_splitk(ad.data_ptr(), wd.data_ptr(), part1.data_ptr(), M, N, K, 1, -1, L.stream_ptr()), "splitk")
+    x1, y1 = x0.cuda(), torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_layernorm_reduce_bf16(x1.data_ptr(), part1.data_ptr(), 1, bd.data_ptr(), gd.data_ptr(), btd.data_ptr(),
+                                             y1.data_ptr(), M, N, 1e-6, L.stream_ptr()), "layernorm_reduce")
+    x2, y2 = x0.cuda(), torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.hmm_op_gemm_bf16(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), x2.data_ptr(), M, N, K, EPI_BIAS_RESID_F32, L.stream_ptr()), "gemm")
+    L.check(lib.hmm_op_layernorm_bf16(x2.data_ptr(), gd.data_ptr(), btd.data_ptr(), y2.data_ptr(), M, N, 1e-6, L.stream_ptr()), "layernorm")
+    assert torch.equal(x1, x2) and torch.equal(y1, y2)
+
+
+def test_gemm_split_k_argument_errors():
+    L, lib = _lib()
+    a = torch.zeros(64, 1024, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(1024, 1024, dtype=torch.bfloat16, device="cuda")
+    part = torch.zeros(4 * 64, 1024, device="cuda")
+    st = L.stream_ptr()
+    assert lib.hmm_op_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), part.data_ptr(), 64, 1024, 1024, 3, -1, st) == -1    # 1024 / 3
+    assert lib.hmm_op_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), part.data_ptr(), 64, 1024, 1024, 9, -1, st) == -1
+    assert lib.hmm_op_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), part.data_ptr(), 64, 1024, 1024, 2, 3, st) == -1     # ping-pong tile
+    assert lib.hmm_op_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), part.data_ptr(), 64, 1024, 1024, 8, 10, st) == -1    # K/8 = 128: no K4 ring
+    assert lib.hmm_op_gemm_bf16_splitk(None, w.data_ptr(), part.data_ptr(), 64, 1024, 1024, 2, -1, st) == -1
+    assert lib.hmm_op_layernorm_reduce_bf16(part.data_ptr(), part.data_ptr(), 0, part.data_ptr(), part.data_ptr(), part.data_ptr(),
+                                            a.data_ptr(), 64, 1024, 1e-6, st) == -1
+
+
 def _attention_ref(qkv, B, T, H, dh, bias_k=None, bias_v=None):
     D = H * dh
     q, k, v = qkv.float().reshape(B, T, 3, H, dh).unbind(2)          # (B,T,H,dh)

@@ -223,6 +223,16 @@ def test_error_codes_through_the_c_abi():
     assert call(store=rows.data_ptr() + 4) == -1 and b"aligned" in lib.hmm_last_error()
     with pytest.raises(L.HippoMMHipError):
         L.check(call(k=-3), "hmm_cosine_topk_prefilter")
+    # the per-event entry point: no segments / k = 0 on a non-empty store are argument errors, not a host division by zero
+    offs = torch.tensor([0, n], dtype=torch.int64, device="cuda")
+    seg_ws = torch.empty(max(lib.hmm_cosine_topk_segmented_prefilter_workspace_bytes(n, 1, k), 1024), dtype=torch.uint8, device="cuda")
+    seg = lambda n_seg, kk: lib.hmm_cosine_topk_segmented_prefilter(rows.data_ptr(), shadow.data_ptr(), n, 1024, q.data_ptr(), offs.data_ptr(),
+                                                                     n_seg, kk, idx.data_ptr(), sims.data_ptr(), n_out.data_ptr(),
+                                                                     seg_ws.data_ptr(), seg_ws.numel(), st)
+    assert seg(1, k) == 0 and int(n_out.item()) == k
+    assert seg(0, k) == -1 and b"n_segments" in lib.hmm_last_error()
+    assert seg(-2, k) == -1
+    assert seg(1, 0) == -1
 
 
 def test_feature_store_with_shadow_serves_the_drop_in_call_identically():
