@@ -58,6 +58,8 @@ FRAMES_PER_GPU = 256           # cfg2
 CFG5_FRAMES = 3600             # cfg5: one hour at 1 fps
 SCENE_LEN = 6                  # frames per synthetic scene
 SCAN_ROWS, SCAN_K = 1_000_000, 32
+LAUNCH_TIMEOUT_S = 1500.0      # wall-clock limit of a self-launched multi-rank run (HMM_BENCH_LAUNCH_TIMEOUT_S overrides)
+SCAN_WARM_MS = 60.0            # every scan leg is timed in steady state: see event_time_ms
 # Rehearsal of the N > 1 code path on a box with fewer GPUs (HMM_BENCH_REHEARSAL=1): every rank uses cuda:0 and the
 # collectives run over gloo.  Exercises launch, sharding, gathers, merges and the JSON line -- NOT RCCL, and the
 # numbers are meaningless (the ranks share one GPU); the line says so and is never a result.
@@ -106,7 +108,27 @@ def launch_ranks(n: int, argv) -> int:
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.setdefault("NCCL_DEBUG", "VERSION")                  # one stderr line naming the RCCL build the ranks loaded
-    return subprocess.run(cmd, env=env).returncode
+    # The ranks are a fresh process group of their own: if they are not done within the wall-clock limit (a rank stuck in a
+    # collective, a rendezvous that never completes) the whole group is killed and the run fails loudly instead of hanging the
+    # box.  Nothing here re-executes a process that has touched the GPU: the parent never has, the children are new.
+    limit = float(os.environ.get("HMM_BENCH_LAUNCH_TIMEOUT_S", LAUNCH_TIMEOUT_S))
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {n} ranks did not finish within {limit:.0f} s; killing their process group", file=sys.stderr)
+        import signal
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 5
 
 
 # ------------------------------------------------------------------------------------------------
@@ -192,9 +214,22 @@ def mfma_roofline(flops: float, ms: float, scope: str) -> dict:
             "flops_accounting": "nominal (reference's un-folded patch conv, every block on every token)"}
 
 
-def event_time_ms(fn, iters, warmup=2):
+def event_time_ms(fn, iters, warmup=2, warm_ms=0.0):
+    """Mean ms per call over `iters` back-to-back calls (HIP events on the current stream) after `warmup` calls and, when
+    `warm_ms` > 0, after at least that many milliseconds of the same calls: sub-millisecond kernels timed right after the
+    device has idled -- a read-back, host work -- run their first 10-30 launches 10-25 % slow while the clocks come back up
+    (tools/multi_thermal_probe.py, profiles/r5_multi_thermal.json: the 16-query scan 0.85 / 0.70 / 0.67 / 0.66 / 0.65 ms over its
+    first five groups of ten launches).  That, not the kernel, was round 4's batched_16_queries 0.672 -> 0.765 ms: the leg had
+    moved behind a read-back and was timed over launches 4-13."""
     for _ in range(warmup):
         fn()
+    if warm_ms > 0:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < warm_ms:
+            for _ in range(8):
+                fn()
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -339,12 +374,13 @@ def scan_bench(do_cpu):
         rows[s:s + 125_000] = blk / blk.norm(dim=1, keepdim=True)
     q = torch.randn(1024, generator=torch.Generator(device="cuda").manual_seed(43), device="cuda")
     store = FeatureStore(rows)
-    ms_query = event_time_ms(lambda: store.search_device(q, SCAN_K), 20, warmup=3)
+    ms_query = event_time_ms(lambda: store.search_device(q, SCAN_K), 50, warmup=3, warm_ms=SCAN_WARM_MS)
     # the streaming kernel alone (dominant kernel of the scan)
     lib = L.load()
     cand = torch.empty(2048 * SCAN_K, dtype=torch.int64, device="cuda")
     ms_kernel = event_time_ms(lambda: L.check(lib.hmm_op_scan_topk_only(rows.data_ptr(), SCAN_ROWS, q.data_ptr(), SCAN_K,
-                                                                        cand.data_ptr(), L.stream_ptr()), "scan"), 20)
+                                                                        cand.data_ptr(), L.stream_ptr()), "scan"), 50,
+                             warm_ms=SCAN_WARM_MS)
     algo_bytes = SCAN_ROWS * 4096.0
     traffic, src = profile_summary("r*_scan_pmc_summary.json", "scan_topk_kernel")
     out = {
@@ -360,7 +396,7 @@ def scan_bench(do_cpu):
     # the fp32 store): candidates from one pass over the shadow, exact fp32 re-score -> the same indices and similarity bits
     store.build_shadow()
     stats = torch.zeros(2, dtype=torch.int32, device="cuda")
-    ms_pre = event_time_ms(lambda: store.search_prefiltered_device(q, SCAN_K, stats), 20, warmup=3)
+    ms_pre = event_time_ms(lambda: store.search_prefiltered_device(q, SCAN_K, stats), 50, warmup=3, warm_ms=SCAN_WARM_MS)
     i_ex, s_ex = store.search_device(q, SCAN_K)
     i_pre, s_pre = store.search_prefiltered_device(q, SCAN_K, stats)
     shadow_bytes = SCAN_ROWS * 2048.0
@@ -378,7 +414,7 @@ def scan_bench(do_cpu):
         "extra_hbm_bytes_held": shadow_bytes}
     # batched questions: 16 queries per pass over the same store
     q16 = torch.randn(16, 1024, generator=torch.Generator(device="cuda").manual_seed(44), device="cuda")
-    ms_multi = event_time_ms(lambda: store.search_multi_device(q16, SCAN_K), 10, warmup=3)
+    ms_multi = event_time_ms(lambda: store.search_multi_device(q16, SCAN_K), 50, warmup=3, warm_ms=SCAN_WARM_MS)
     out["batched_16_queries"] = {"ms_per_pass": round(ms_multi, 4), "us_per_query": round(ms_multi / 16 * 1e3, 1),
                                  "store_read_GBps": round(algo_bytes / ms_multi / 1e6, 1),
                                  "hbm_frac": round(algo_bytes / ms_multi / 1e6 / PEAK_HBM_GBS, 4),
@@ -388,7 +424,7 @@ def scan_bench(do_cpu):
     def torch_scan():
         sims = (rows @ q) / (rows.norm(dim=1) * q.norm())
         return torch.topk(sims, SCAN_K)
-    ms_torch = event_time_ms(torch_scan, 10, warmup=3)
+    ms_torch = event_time_ms(torch_scan, 10, warmup=3, warm_ms=SCAN_WARM_MS)
     out["torch_rocm_reference"] = {"ms_per_query": round(ms_torch, 4), "GBps": round(algo_bytes / ms_torch / 1e6, 1),
                                    "what": "rows @ q / (rows.norm(dim=1) * q.norm()) + torch.topk on the same GPU"}
     if do_cpu:
@@ -457,11 +493,12 @@ def retrieval_bench(rows, do_cpu):
         t0 = time.perf_counter()
         top2 = ask_device_ranked()
         t2.append(time.perf_counter() - t0)
-    t_tower = event_time_ms(lambda: tower.forward_into(tok([question]).cuda(), emb), 10, warmup=2)
+    t_tower = event_time_ms(lambda: tower.forward_into(tok([question]).cuda(), emb), 10, warmup=2, warm_ms=SCAN_WARM_MS)
     q = emb[0].clone()
-    t_scan = event_time_ms(lambda: events.search_segments_device(q, events.offsets, 5), 10, warmup=2)
+    t_scan = event_time_ms(lambda: events.search_segments_device(q, events.offsets, 5), 30, warmup=2, warm_ms=SCAN_WARM_MS)
     events.build_shadow()
-    t_scan_pre = event_time_ms(lambda: events.search_segments_device(q, events.offsets, 5, prefilter=True), 10, warmup=2)
+    t_scan_pre = event_time_ms(lambda: events.search_segments_device(q, events.offsets, 5, prefilter=True), 30, warmup=2,
+                               warm_ms=SCAN_WARM_MS)
     ex, pre = events.search_segments_device(q, events.offsets, 5), events.search_segments_device(q, events.offsets, 5, prefilter=True)
     pre_same = bool(torch.equal(ex[0], pre[0]) and torch.equal(ex[1].view(torch.int32), pre[1].view(torch.int32)) and torch.equal(ex[2], pre[2]))
     # the reference's loop UNCHANGED (hippocampal_memory.py:3143-3153): one top_k_cosine_similarity call per event with the event's
@@ -491,7 +528,11 @@ def retrieval_bench(rows, do_cpu):
            "ms_per_event_scan_bf16_prefilter": round(t_scan_pre, 3), "prefilter_identical_to_fp32_scan": pre_same,
            "unchanged_reference_loop_ms_per_event": {"numpy_store_uploaded_per_call": round(ms_upload, 4),
                                                      "with_enable_store_cache": round(ms_cached, 4), "events_timed": 100,
-                                                     "rows_per_event": per_event},
+                                                     "rows_per_event": per_event,
+                                                     "store_cache_semantics": "opt-in; every call hashes the WHOLE host array "
+                                                     "(xxh3, arrays <= 64 MB) before it trusts the resident copy, so an in-place "
+                                                     "edit is a miss; above 64 MB only a 64 x 16 sample is compared "
+                                                     "(hippomm_amd.vector_ops.enable_store_cache)"},
            "ms_end_to_end_ranked_on_device": round(sorted(t2)[len(t2) // 2] * 1e3, 3),
            "device_ranking_equals_host_ranking": [(e, i) for e, i, _ in top2] == [(e, i) for _, e, i in top]}
     if do_cpu:
@@ -741,7 +782,7 @@ def sharded_scan_bench(rank, world, reduce_max, rows_per_gpu=None, strong=True):
         separated = below & above                                # a rank is pinned only when BOTH neighbours are clear of it
         ok = bool(idx.numel() == SCAN_K and torch.equal(idx[separated], want[:SCAN_K][separated]))
         dist.barrier()
-        ms = reduce_max(event_time_ms(query, 20, warmup=3))
+        ms = reduce_max(event_time_ms(query, 50, warmup=3, warm_ms=SCAN_WARM_MS))
         total = float(n_local) * world * 4096.0
         out[tag] = {"rows_per_gpu": n_local, "ms_per_query": round(ms, 4), "GBps_all_gpus": round(total / ms / 1e6, 1),
                     "frac_of_n_gpus_x_8TBps": round(total / ms / 1e6 / (PEAK_HBM_GBS * world), 4),
@@ -927,6 +968,9 @@ def main():
                                        "(the dominant GEMM) on its own 2MNK")
         roof, table = gemm_roofline(FRAMES_PER_GPU)
         line["roofline"], line["kernels"] = roof, table
+        line["kernels_note"] = ("NOT additive: each kernel of one block is timed between its own HIP events in ONE full-batch chain "
+                                "(event gaps included), while the timed step runs two half-batch chains that overlap on the chip; "
+                                "32 x the column sums to more than ms_per_step")
         if sharded_scan is not None:
             line["scan"] = sharded_scan
         if REHEARSAL:

@@ -357,6 +357,7 @@ namespace hmm {
 HMM_TUNABLE(int, g_enc_cls_fork, 1)      // probe build: 0 = cls-row projection on the chain's own stream (A/B)
 HMM_TUNABLE(int, g_enc_fused_min_vision, 32) // frames of a forward from which in_proj + attention run as the fused kernel
 HMM_TUNABLE(int, g_enc_fused_min_audio, 6)   // clips (3 per segment) likewise
+HMM_TUNABLE(int, g_enc_mlp_chunk_rows, 0)  // probe build: > 0 = fc1 -> fc2 per chunk of this many token rows, the hidden activation of every chunk in the SAME buffer (round 5's energy experiment: keep it inside the 256-MB Infinity Cache; measured, not kept -- profiles/r5_mlp_chunk_probe.json)
 HMM_TUNABLE(int, g_enc_sliver_rows, 16448) // token rows of a forward (batch x clips x tokens) up to which few-row GEMMs may use the sliver kernel
 
 struct Chain {                 // one (half-)batch travelling through the tower on one stream
@@ -387,6 +388,21 @@ static int chain_tokens(hmm_encoder* e, const Chain& c) {
     HMM_TRY(gemm_bf16(im2col, e->patch_w, nullptr, patch, n_img * e->n_patches, D, e->patch_k_pad, HMM_EPI_F32, c.tile, c.st));
     HMM_TRY(launch_assemble_tokens(patch, e->cls, e->pos, e->stem_g, e->stem_b, 1e-5f, e->pre_g, e->pre_b, 1e-6f,
                                    x, n_img, e->T, D, c.st));
+    return HMM_OK;
+}
+
+// fc1 + GELU then fc2 + residual on R rows.  Chunked (probe build only): the hidden activation of each chunk lives in the first
+// `chunk` rows of `big`, so that fc2 reads what fc1 has just written from the Infinity Cache instead of HBM.
+static int mlp_pair(hmm_encoder* e, const Chain& c, const BlockW& w, const bf16_t* a, bf16_t* big, float* x, int R) {
+    const int D = e->D;
+    const int chunk = g_enc_mlp_chunk_rows > 0 && g_enc_mlp_chunk_rows < R ? g_enc_mlp_chunk_rows : R;
+    for (int r0 = 0; r0 < R; r0 += chunk) {
+        const int rows = R - r0 < chunk ? R - r0 : chunk;
+        int rc = gemm_bf16(a + (size_t)r0 * D, w.fc1_w, w.fc1_b, big, rows, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, c.tile, c.st);
+        if (rc != HMM_OK) return rc;
+        rc = gemm_bf16(big, w.fc2_w, w.fc2_b, x + (size_t)r0 * D, rows, D, e->mlp, HMM_EPI_BIAS_RESID_F32, c.tile, c.st);
+        if (rc != HMM_OK) return rc;
+    }
     return HMM_OK;
 }
 
@@ -429,8 +445,7 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
         HMM_TRY(qkv_attention_bf16(a, w.qkv_w, w.qkv_b, hc, big, n_img, st));
         HMM_TRY(gemm_bf16(big, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, c.tile, st));
         HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
-        HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, c.tile, st));
-        HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, c.tile, st));
+        HMM_TRY(mlp_pair(e, c, w, a, big, x, R));
     } else if (i + 1 < e->depth && e->fused_attention && c.fuse && e->tower == HMM_TOWER_AUDIO && D == 768 && e->heads == 12 && T == 229 &&
                e->bias_kv) {
         // audio: in_proj + attention in one kernel per (clip, head); every row of a clip fits the 256-row tile, so there is

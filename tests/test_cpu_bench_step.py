@@ -143,3 +143,35 @@ def test_gpu_count_comes_from_sysfs_not_from_hip(tmp_path, monkeypatch):
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
     assert bench.visible_gpu_count(str(tmp_path)) == 1
     assert bench.visible_gpu_count(str(tmp_path / "absent")) == 0
+
+
+def test_self_launch_kills_ranks_that_hang(monkeypatch, tmp_path, capsys):
+    """launch_ranks gives the ranks a wall-clock limit: a group that does not finish (a rank stuck in a collective) is killed --
+    children and grandchildren, they are a process group of their own -- and the run returns non-zero instead of hanging."""
+    import time
+    import bench
+    marker = tmp_path / "grandchild.pid"
+    script = tmp_path / "hang.py"
+    script.write_text("import os, subprocess, sys, time\n"
+                      f"p = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)'])\n"
+                      f"open({str(marker)!r}, 'w').write(str(p.pid))\n"
+                      "time.sleep(600)\n")
+    monkeypatch.setenv("HMM_BENCH_REHEARSAL", "1")
+    monkeypatch.setattr(bench, "REHEARSAL", True)                       # no GPU count needed
+    monkeypatch.setenv("HMM_BENCH_LAUNCH_TIMEOUT_S", "3")
+    real_popen = bench.subprocess.Popen
+    monkeypatch.setattr(bench.subprocess, "Popen",
+                        lambda cmd, **kw: real_popen([bench.sys.executable, str(script)], **kw))   # stand-in for torch.distributed.run
+    t0 = time.time()
+    rc = bench.launch_ranks(2, ["--gpus", "2"])
+    assert rc == 5 and time.time() - t0 < 30
+    assert "did not finish within 3 s" in capsys.readouterr().err
+    pid = int(marker.read_text())
+    for _ in range(50):                                                  # the grandchild went with the group
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("a grandchild of the killed launch is still alive")

@@ -28,7 +28,7 @@ def test_fingerprint_sees_identity_layout_and_every_value_of_event_sized_arrays(
     rng = np.random.default_rng(0)
     a = rng.standard_normal((300, 1024)).astype(np.float32)
     fp = cache.fingerprint(a)
-    assert fp == cache.fingerprint(a) and "crc32" in fp
+    assert fp == cache.fingerprint(a) and ("xxh3_64" in fp or "crc32" in fp)
     assert cache.fingerprint(a.copy()) != fp                                  # another buffer
     assert cache.fingerprint(a[:299]) != fp                                   # another shape
     assert cache.fingerprint(a.view(np.int32)) != fp                          # another dtype

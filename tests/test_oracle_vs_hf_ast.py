@@ -24,9 +24,9 @@ transformers = pytest.importorskip("transformers")
 DEPTH = 2
 
 
-def _ast():
+def _ast(depth=DEPTH):
     from transformers import ASTConfig, ASTModel
-    cfg = ASTConfig(hidden_size=768, num_hidden_layers=DEPTH, num_attention_heads=12, intermediate_size=3072, hidden_act="gelu",
+    cfg = ASTConfig(hidden_size=768, num_hidden_layers=depth, num_attention_heads=12, intermediate_size=3072, hidden_act="gelu",
                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=1e-6, patch_size=16,
                     frequency_stride=10, time_stride=10, max_length=204, num_mel_bins=128)
     hf = ASTModel(cfg).eval()
@@ -34,8 +34,8 @@ def _ast():
     return hf
 
 
-def _blocks_from_ast(sd, st, tr):
-    for i in range(DEPTH):
+def _blocks_from_ast(sd, st, tr, depth=DEPTH):
+    for i in range(depth):
         h, b = f"layers.{i}.", f"{tr}blocks.{i}."
         st[b + "norm_1.weight"], st[b + "norm_1.bias"] = sd[h + "layernorm_before.weight"], sd[h + "layernorm_before.bias"]
         st[b + "norm_2.weight"], st[b + "norm_2.bias"] = sd[h + "layernorm_after.weight"], sd[h + "layernorm_after.bias"]
@@ -71,13 +71,14 @@ def test_audio_patch_grid_matches_hf_ast():
     assert (got[:, 1:] - other).abs().max().item() > 0.1
 
 
-def test_audio_trunk_geometry_matches_hf_ast():
-    hf = _ast()
+@pytest.mark.parametrize("depth", [DEPTH, 12])          # 12 = imagebind_huge's audio depth: the whole trunk, not a 2-block sample
+def test_audio_trunk_geometry_matches_hf_ast(depth):
+    hf = _ast(depth)
     sd = hf.state_dict()
     tr, hd = "modality_trunks.audio.", "modality_heads.audio."
     st = {}
-    _blocks_from_ast(sd, st, tr)
-    spec = ib.reduced(ib.AUDIO_HUGE, DEPTH)
+    _blocks_from_ast(sd, st, tr, depth)
+    spec = ib.reduced(ib.AUDIO_HUGE, depth)
     x = torch.randn(2, 204, 128, generator=torch.Generator().manual_seed(13))
     with torch.no_grad():
         tokens = hf.embeddings(x)                                   # (2, 230, 768): cls, distillation, 228 patches, + positions
