@@ -421,7 +421,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_body(f32x4 (&acc)[8][4], const
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int it = g * 4 + i, row = q * 32 + it * 4 + rsub;
-                xin[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (GUARD) xin[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!GUARD || row < rows_left) {                 // streamed once: non-temporal (out-proj -2 % in the tower, -12 % alone)
                     const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Cw + (q * 8 + it) * row_step + lane_off));
                     xin[it] = make_float4(t[0], t[1], t[2], t[3]);
@@ -501,7 +501,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[8][4], const floa
 // ------------------------------------------------------------------------------------------------
 // Ping-pong kernel: 256x256x64 tiles, 8 waves; the K loop lives in gemm_pp_mainloop.h (shared with the fused
 // in_proj + attention kernel).  Tiles are walked in plain strips (whole row tiles, XCD-contiguous); ablations, tile-walk and
-// pipeline variants that were measured and rejected are recorded in DESIGN.md section 4.3 / 4.5, not kept in the code.
+// pipeline variants that were measured and rejected are recorded in profiles/LABNOTES.md section 4.3 / 4.5, not kept in the code.
 // ------------------------------------------------------------------------------------------------
 // Tile walk inside the XCD-contiguous order: 0 = strips (a row tile's column tiles are consecutive); (R << 8) | C = blocks of
 // R row tiles x C column tiles.  Strips re-stream the whole weight matrix from the Infinity Cache once per row tile (fc1:
@@ -595,7 +595,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(
 #ifdef HMM_PROBE
     if (stamps && threadIdx.x == 0) stamps[(size_t)bid * 8 + 7] = __builtin_amdgcn_s_memtime();     // shader-clock ticks
 #endif
-    gemm_epilogue_lds<EPI>(acc, bias, Cout, M, N, m0 + wm * 128, n0 + wn * 64, smem + wave * kEpiSlab, lane);
+    // the epilogue's lane-derived indices (lane >> 4, lane & 15, ...) are recomputed HERE from an opaque copy of the lane id:
+    // hoisted in front of the main loop they were carried across it and two of them spilled to scratch in the fp32 epilogues
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    gemm_epilogue_lds<EPI>(acc, bias, Cout, M, N, m0 + wm * 128, n0 + wn * 64, smem + wave * kEpiSlab, lane_e);
 #ifdef HMM_PROBE
     if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     HMM_STAMP(3)
@@ -627,6 +631,65 @@ static int launch_gemm_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
 HMM_TUNABLE(int, g_gemm_col_major, 0)
 static thread_local int t_gemm_tail_launch = 0;       // the peeled tail of a big launch keeps the row-major list (set by gemm_bf16)
 static thread_local int t_gemm_splits = 1;            // > 1: the next launch_gemm is a split-K launch (set by gemm_bf16_splitk)
+
+// Split-K on the ping-pong tile, for the N = 1280 GEMM with the long K of a MID-size forward (8 ... 48 frames): fc2 of a 16-frame
+// chain is 85 tiles of 256 x 256 walking 80 K-tiles each -- a third of the chip busy for ~110 us.  `splits` workgroups per tile
+// take K-pair ranges of near-equal length (40 pairs over 3 splits: 14 / 13 / 13; the ranges depend on (K, splits) only) and
+// store their fp32 accumulators, no bias, to slab[split][M][N]; launch_layernorm_reduce_bf16 adds the slabs in split order.
+__global__ __launch_bounds__(512) void gemm_bf16_pp_splitk_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, float* __restrict__ part, int M, int N, int K,
+    int tiles_n, int tiles, int splits) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int split = swz / tiles, tl = swz - split * tiles;
+    const int m0 = (tl / tiles_n) * 256, n0 = (tl % tiles_n) * 256;
+    const int pairs = K >> 7, base = pairs / splits, rem = pairs % splits;            // K-tile pairs: the first `rem` splits take one more
+    const int p0 = split * base + (split < rem ? split : rem), np = base + (split < rem ? 1 : 0);
+
+    PPSources src;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int lr = (wave + 8 * j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((lr >> 1) & 7);
+        const int arow = (lr & 63) + (lr >> 6) * 128;
+        int g0 = m0 + arow, g1 = m0 + arow + 64;
+        g0 = g0 < M ? g0 : M - 1;
+        g1 = g1 < M ? g1 : M - 1;
+        src.alo[j] = g0 * K + c * 8;
+        src.ahi[j] = g1 * K + c * 8;
+        const int bcol = (lr >> 5) * 64 + (lr & 31);
+        src.blo[j] = (n0 + bcol) * K + c * 8;
+        src.bhi[j] = (n0 + bcol + 32) * K + c * 8;
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pp_mainloop(A + (size_t)p0 * 128, W + (size_t)p0 * 128, src, 2 * np, smem, lane, wave, acc);
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    gemm_epilogue_lds<HMM_EPI_F32>(acc, nullptr, part + (size_t)split * M * N, M, N, m0 + wm * 128, n0 + wn * 64,
+                                   smem + wave * kEpiSlab, lane_e);
+}
+
+static int launch_gemm_pp_splitk(const bf16_t* A, const bf16_t* W, float* part, int M, int N, int K, int splits, hipStream_t st) {
+    constexpr int LDS = 8 * kEpiSlab > 2 * 4 * 16384 ? 8 * kEpiSlab : 2 * 4 * 16384;
+    HMM_REQUIRE(N % 256 == 0 && K % 128 == 0 && (K >> 7) >= splits, HMM_E_INVALID,
+                "gemm_splitk: the ping-pong tile needs N %% 256 == 0, K %% 128 == 0 and K / 128 >= splits (N=%d K=%d splits=%d)", N, K, splits);
+    HMM_REQUIRE((size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31), HMM_E_INVALID, "gemm_splitk: operand too large for 32-bit staging offsets");
+    const int tiles_m = (M + 255) / 256, tiles_n = N / 256, tiles = tiles_m * tiles_n;
+    auto kern = gemm_bf16_pp_splitk_kernel;
+    HMM_ENSURE_DYN_LDS(kern, LDS);
+    kern<<<tiles * splits, 512, LDS, st>>>(A, W, part, M, N, K, tiles_n, tiles, splits);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
 
 template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2, int KSUB = 1>
 static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
@@ -727,7 +790,7 @@ static int launch_gemm_epi(const bf16_t* A, const bf16_t* W, const float* bias, 
 // 64x64 tiles behind the four-buffer ring (64 KiB of LDS: two workgroups per CU).  Measured and not kept, both bitwise equal:
 // eight buffers (seven K-tiles in flight, one workgroup per CU) 0.29 us per K-tile instead of 0.225; five buffers with the
 // fragments of the next K-tile read under the MFMAs of the current one 0.25 -- the step is the barrier, the DMA issue and the
-// dependent read -> MFMA chain, not bytes in flight; eight waves of 32x16 per tile (two per SIMD) 0.25.
+// dependent read -> MFMA chain, not bytes in flight; eight waves of 32x16 per tile (two per SIMD) 0.25 (profiles/LABNOTES.md 4.8).
 static int launch_gemm_ring64_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                                   int epi, hipStream_t st) {
 #define HMM_CALL(E) launch_gemm<64, 64, 2, 2, E, 4>(A, W, bias, C, M, N, K, st)
@@ -769,6 +832,25 @@ static int launch_gemm_ringk_epi(const bf16_t* A, const bf16_t* W, const float* 
     }
 #undef HMM_CALL
     set_error("gemm: deep-K tiles have no epilogue %d", epi);
+    return HMM_E_INVALID;
+}
+
+// Rectangular tiles behind the ring (round 5): with few rows the chip is filled by COLUMN tiles, and what a launch then costs is
+// its K walk times the workgroups a CU has to run one after (or beside) the other.  One frame's qkv GEMM is 300 tiles of 64 x 64
+// on 256 CUs -- 44 CUs run two workgroups and the launch takes their time, 13.3 us; as 128 x 64 tiles it is 180 workgroups, one per
+// CU, and the tile's 16 MFMAs per wave and K-tile hide the ring's latencies better than the 8 of a 64 x 64 tile.
+template <int BM, int BN>
+static int launch_gemm_ring_rect_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                                     int epi, hipStream_t st) {
+#define HMM_CALL(E) launch_gemm<BM, BN, 2, 2, E, 4>(A, W, bias, C, M, N, K, st)
+    switch (epi) {
+        case HMM_EPI_BIAS_BF16:      return HMM_CALL(HMM_EPI_BIAS_BF16);
+        case HMM_EPI_BIAS_GELU_BF16: return HMM_CALL(HMM_EPI_BIAS_GELU_BF16);
+        case HMM_EPI_BIAS_RESID_F32: return HMM_CALL(HMM_EPI_BIAS_RESID_F32);
+        case HMM_EPI_F32:            return HMM_CALL(HMM_EPI_F32);
+    }
+#undef HMM_CALL
+    set_error("gemm: rectangular ring tiles have no epilogue %d", epi);
     return HMM_E_INVALID;
 }
 
@@ -875,6 +957,8 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         case HMM_GEMM_TILE_64x64_RING_K2: return launch_gemm_ringk_epi<64, 3, 2>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_32x32_RING_K2: return launch_gemm_ringk_epi<32, 4, 2>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_32x32_RING_K4: return launch_gemm_ringk_epi<32, 4, 4>(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_128x64_RING:   return launch_gemm_ring_rect_epi<128, 64>(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_64x128_RING:   return launch_gemm_ring_rect_epi<64, 128>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_256x256_PP: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_128x128:    return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_256x128:    return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
@@ -892,9 +976,11 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
 HMM_TUNABLE(int, g_gemm_splitk_tile, -1)     // probe build: force a ring geometry for the split launches
 int gemm_bf16_splitk(const bf16_t* A, const bf16_t* W, float* part, int M, int N, int K, int splits, int tile, hipStream_t st) {
     HMM_REQUIRE(A && W && part, HMM_E_INVALID, "gemm_splitk: null pointer");
-    HMM_REQUIRE(M >= 1 && N >= 128 && N % 128 == 0 && splits >= 1 && splits <= 8 && K % (64 * splits) == 0, HMM_E_INVALID,
+    HMM_REQUIRE(M >= 1 && N >= 128 && N % 128 == 0 && splits >= 1 && splits <= 8, HMM_E_INVALID,
                 "gemm_splitk: unsupported shape M=%d N=%d K=%d splits=%d", M, N, K, splits);
     if (g_gemm_splitk_tile >= 0) tile = g_gemm_splitk_tile;
+    if (tile == HMM_GEMM_TILE_256x256_PP) return launch_gemm_pp_splitk(A, W, part, M, N, K, splits, st);   // near-equal K ranges
+    HMM_REQUIRE(K % (64 * splits) == 0, HMM_E_INVALID, "gemm_splitk: K = %d is not a multiple of 64 x %d splits", K, splits);
     const int k_len = K / splits;
     if (tile < 0) {
         // by the number of 64 x 64 workgroups (profiles/r5_splitk_probe.json, cold weights): under half a chip of them, 32 x 32
@@ -916,6 +1002,8 @@ int gemm_bf16_splitk(const bf16_t* A, const bf16_t* W, float* part, int M, int N
         case HMM_GEMM_TILE_64x64_RING_K2: rc = launch_gemm<64, 64, 2, 2, HMM_EPI_F32, 3, 2>(A, W, nullptr, part, M, N, K, st); break;
         case HMM_GEMM_TILE_32x32_RING_K2: rc = launch_gemm<32, 32, 2, 2, HMM_EPI_F32, 4, 2>(A, W, nullptr, part, M, N, K, st); break;
         case HMM_GEMM_TILE_32x32_RING_K4: rc = launch_gemm<32, 32, 2, 2, HMM_EPI_F32, 4, 4>(A, W, nullptr, part, M, N, K, st); break;
+        case HMM_GEMM_TILE_128x64_RING:   rc = launch_gemm<128, 64, 2, 2, HMM_EPI_F32, 4>(A, W, nullptr, part, M, N, K, st); break;
+        case HMM_GEMM_TILE_64x128_RING:   rc = launch_gemm<64, 128, 2, 2, HMM_EPI_F32, 4>(A, W, nullptr, part, M, N, K, st); break;
         default:
             set_error("gemm_splitk: tile geometry %d has no split-K launch", tile);
             rc = HMM_E_INVALID;

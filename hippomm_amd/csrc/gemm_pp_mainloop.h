@@ -18,7 +18,7 @@
 // The LDS image of a half-tile is lane-linear for the DMA (1 KiB = 8 rows x 128 B per wave-instruction); the bank
 // swizzle chunk' = chunk ^ ((row >> 1) & 7) is applied to the per-lane SOURCE address by the caller (PPSources) and on
 // the ds_read_b128 side here.
-// Ablations, tile-walk and pipeline variants that were measured and rejected are recorded in DESIGN.md 4.3 / 4.5.
+// Ablations, tile-walk and pipeline variants that were measured and rejected are recorded in profiles/LABNOTES.md 4.3 / 4.5.
 #pragma once
 #include "hmm_common.h"
 

@@ -1,5 +1,5 @@
 // Probe (tools/libhippomm_probe.so only): what read bandwidth does HBM deliver to a kernel that does nothing but stream?
-// The ceiling the scan kernels are measured against in DESIGN.md 4.1.  Grid-stride over `n_bytes` in float4 pieces,
+// The ceiling the scan kernels are measured against in profiles/LABNOTES.md 4.1.  Grid-stride over `n_bytes` in float4 pieces,
 // `unroll` independent 16-B loads per lane in flight (1 KiB per wave and load), non-temporal or default cache policy.
 #include "hmm_common.h"
 
