@@ -43,14 +43,6 @@ HMM_TUNABLE(int, g_enc_splitk_rows_vision, 300)   // the same for the vision tow
 HMM_TUNABLE(int, g_enc_splitk_fc2, 2)      // K splits of fc2 (K = 4D), vision and audio towers (four: one frame 2.25 -> 2.27 ms, one segment 0.67 -> 0.69)
 HMM_TUNABLE(int, g_enc_splitk_fc2_text, 4) // the same for the text tower (two / four splits: one question 0.988 / 0.992 ms, two 1.07 / 1.04, four 1.27 / 1.23; unsplit 1.04 / 1.10 / 1.37)
 HMM_TUNABLE(int, g_enc_splitk_out, 1)      // K splits of out-proj (K = D); 1 = the residual epilogue as in every other regime
-// MID-size vision forwards (the reference's segment and frame-buffer calls: 8 ... 32 frames, hippocampal_memory.py:1180, :1328): fc2
-// of a 16-frame chain is 85 ping-pong tiles walking 80 K-tiles each on 256 CUs.  Between g_enc_splitk_mid_lo and _hi token rows per
-// forward it runs as gemm_bf16_pp_splitk (three near-equal K ranges per tile, fp32 slabs) reduced by the next norm_1 -- in the
-// fused-attention path out of place into a second residual buffer, because the cls-row LayerNorm on the forked stream reads
-// the same rows at the same time.  A third regime for the bits of fc2 (tests/test_gpu_encoder_batch.py).
-HMM_TUNABLE(int, g_enc_splitk_mid_lo, 2056)   // 8 frames
-HMM_TUNABLE(int, g_enc_splitk_mid_hi, 12336)  // 48 frames; 0 = no mid regime
-HMM_TUNABLE(int, g_enc_splitk_mid, 3)         // K splits of fc2 in the mid regime
 
 enum PackKind { PACK_F32, PACK_BF16, PACK_FOLD_CONV3D };
 
@@ -174,22 +166,19 @@ static void plan_params(hmm_encoder* e, std::vector<std::pair<void**, size_t>>& 
     e->arena_bytes = ab.cursor;
 }
 
-struct WsPlan { int n_img, R; size_t off_x, off_x2, off_a, off_big, off_im2col, off_patch, off_hl, off_hv, off_xc, off_ac, off_qc, off_hc, off_sel, off_part, total; };
+struct WsPlan { int n_img, R; size_t off_x, off_a, off_big, off_im2col, off_patch, off_hl, off_hv, off_xc, off_ac, off_qc, off_hc, off_sel, off_part, total; };
 
-// The split-K regime of a forward of `batch` samples (a property of the whole forward, not of a chain): 0 = none (fc2 keeps its
-// residual epilogue), 1 = few rows (ring tiles, g_enc_splitk_fc2 / _text splits), 2 = mid-size vision forward (ping-pong tiles,
-// g_enc_splitk_mid splits).
+// Whether a forward of `batch` samples is in the few-row split-K regime (a property of the whole forward, not of a chain).
+// (A MID regime -- 8 ... 48 frames, fc2 as split-K on the ping-pong tile -- was built and measured in round 5: -2 ... -8 % at 8-28
+// frames with a different best split factor per size, 0 at the reference's 32-frame buffer, losses above; under the 5 % bar it
+// was removed: profiles/r5_mid_splitk_probe.json, profiles/LABNOTES_r5.md.)
 static int fc2_splits(const hmm_encoder* e) { return e->tower == HMM_TOWER_TEXT ? g_enc_splitk_fc2_text : g_enc_splitk_fc2; }
 static int splitk_mode(const hmm_encoder* e, int batch) {
     const int64_t rows = (int64_t)batch * e->clips * e->T;
     const int limit = e->tower == HMM_TOWER_VISION ? g_enc_splitk_rows_vision : g_enc_splitk_rows;
-    if (limit > 0 && rows <= limit && e->D % (64 * g_enc_splitk_out) == 0 && e->mlp % (64 * fc2_splits(e)) == 0) return 1;
-    if (e->tower == HMM_TOWER_VISION && g_enc_splitk_mid_hi > 0 && rows >= g_enc_splitk_mid_lo && rows <= g_enc_splitk_mid_hi &&
-        e->D % 256 == 0 && e->mlp % 128 == 0 && e->mlp / 128 >= g_enc_splitk_mid)
-        return 2;
-    return 0;
+    return limit > 0 && rows <= limit && e->D % (64 * g_enc_splitk_out) == 0 && e->mlp % (64 * fc2_splits(e)) == 0 ? 1 : 0;
 }
-static int mode_splits(const hmm_encoder* e, int mode) { return mode == 2 ? g_enc_splitk_mid : fc2_splits(e); }
+static int mode_splits(const hmm_encoder* e, int) { return fc2_splits(e); }
 
 static WsPlan ws_plan(const hmm_encoder* e, int batch, int sk_mode) {
     WsPlan p{};
@@ -214,10 +203,9 @@ static WsPlan ws_plan(const hmm_encoder* e, int batch, int sk_mode) {
     p.off_qc = cur;  cur = align_up(cur + (size_t)p.n_img * D * 2, 256);
     p.off_hc = cur;  cur = align_up(cur + (size_t)p.n_img * e->mlp * 2, 256);
     p.off_sel = cur; cur = align_up(cur + (size_t)p.n_img * 4, 256);
-    // split-K partial slabs [splits][R][D] fp32, and (mid regime) the second residual buffer the fused path reduces into
+    // split-K partial slabs [splits][R][D] fp32 (few-row forwards only)
     const int max_splits = mode_splits(e, sk_mode) > g_enc_splitk_out ? mode_splits(e, sk_mode) : g_enc_splitk_out;
     p.off_part = cur; cur = align_up(cur + (sk_mode ? (size_t)max_splits * p.R * D * 4 : 0), 256);
-    p.off_x2 = cur;   cur = align_up(cur + (sk_mode == 2 ? (size_t)p.R * D * 4 : 0), 256);
     p.total = cur + 256;
     return p;
 }
@@ -383,9 +371,8 @@ struct Chain {                 // one (half-)batch travelling through the tower 
     bool fuse;                 // in_proj + attention as one kernel (large enough forwards only, see hmm_encoder_forward)
     int sk_mode;               // splitk_mode() of the forward: fc2 as a split-K launch reduced by the LayerNorm behind it
     mutable const float* pending_bias;   // fc2 of the previous block left partial slabs: the next LayerNorm adds them (+ this bias)
-    mutable int xsel;          // which of the two residual buffers holds x (mid regime, fused path: reduced out of place)
 };
-static float* chain_x(const Chain& c) { return reinterpret_cast<float*>(c.ws + (c.xsel ? c.p.off_x2 : c.p.off_x)); }
+static float* chain_x(const Chain& c) { return reinterpret_cast<float*>(c.ws + c.p.off_x); }
 
 #define HMM_TRY(call) do { int _rc = (call); if (_rc != HMM_OK) return _rc; } while (0)
 
@@ -413,14 +400,6 @@ static int chain_tokens(hmm_encoder* e, const Chain& c) {
 // `chunk` rows of `big`, so that fc2 reads what fc1 has just written from the Infinity Cache instead of HBM.
 static int mlp_pair(hmm_encoder* e, const Chain& c, const BlockW& w, const bf16_t* a, bf16_t* big, float* x, int R) {
     const int D = e->D;
-    if (c.sk_mode == 2) {      // mid regime: fc2's partial products stay in their slabs until the next block's norm_1
-        int rc = gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, c.tile, c.st);
-        if (rc != HMM_OK) return rc;
-        rc = gemm_bf16_splitk(big, w.fc2_w, reinterpret_cast<float*>(c.ws + c.p.off_part), R, D, e->mlp, g_enc_splitk_mid,
-                              HMM_GEMM_TILE_256x256_PP, c.st);
-        if (rc == HMM_OK) c.pending_bias = w.fc2_b;
-        return rc;
-    }
     const int chunk = g_enc_mlp_chunk_rows > 0 && g_enc_mlp_chunk_rows < R ? g_enc_mlp_chunk_rows : R;
     for (int r0 = 0; r0 < R; r0 += chunk) {
         const int rows = R - r0 < chunk ? R - r0 : chunk;
@@ -452,7 +431,7 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
     const float* pending = c.pending_bias;            // fc2 of block i - 1 is still in its slabs: this block's norm_1 adds them
     c.pending_bias = nullptr;
     if (!(i + 1 < e->depth && fused)) {
-        if (pending) HMM_TRY(launch_layernorm_reduce_bf16(x, x, part, part_stride, n_splits, 1, pending, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
+        if (pending) HMM_TRY(launch_layernorm_reduce_bf16(x, part, part_stride, n_splits, pending, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
         else         HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
     }
     if (i + 1 < e->depth && fused) {
@@ -466,23 +445,10 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
             HMM_HIP_CHECK(hipEventRecord(c.ev_x, st));                       // x of this block is final on `st`
             HMM_HIP_CHECK(hipStreamWaitEvent(cst, c.ev_x, 0));
         }
-        if (pending) {
-            // Both LayerNorms add the slabs of the previous fc2 themselves.  The big one writes the updated residual stream to
-            // the OTHER buffer: the cls-row launch on the forked stream reads the same rows of the old one at the same time
-            // (and writes nothing), so neither ever sees a half-updated row.
-            float* x_new = reinterpret_cast<float*>(c.ws + (c.xsel ? p.off_x : p.off_x2));
-            HMM_TRY(launch_layernorm_reduce_bf16(x, nullptr, part, part_stride, n_splits, T, pending, w.ln1_g, w.ln1_b, ac, n_img, D, 1e-6f, cst));
-            HMM_TRY(gemm_bf16(ac, w.qkv_w, w.qkv_b, hc, n_img, 3 * D, D, HMM_EPI_BIAS_BF16, c.tile, cst));
-            if (g_enc_cls_fork) HMM_HIP_CHECK(hipEventRecord(c.ev_cls, cst));
-            HMM_TRY(launch_layernorm_reduce_bf16(x, x_new, part, part_stride, n_splits, 1, pending, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
-            c.xsel ^= 1;
-            x = x_new;
-        } else {
-            HMM_TRY(launch_layernorm_bf16(x, (size_t)T * D, w.ln1_g, w.ln1_b, ac, n_img, D, 1e-6f, cst));     // token 0 of every image
-            HMM_TRY(gemm_bf16(ac, w.qkv_w, w.qkv_b, hc, n_img, 3 * D, D, HMM_EPI_BIAS_BF16, c.tile, cst));
-            if (g_enc_cls_fork) HMM_HIP_CHECK(hipEventRecord(c.ev_cls, cst));
-            HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
-        }
+        HMM_TRY(launch_layernorm_bf16(x, (size_t)T * D, w.ln1_g, w.ln1_b, ac, n_img, D, 1e-6f, cst));     // token 0 of every image
+        HMM_TRY(gemm_bf16(ac, w.qkv_w, w.qkv_b, hc, n_img, 3 * D, D, HMM_EPI_BIAS_BF16, c.tile, cst));
+        if (g_enc_cls_fork) HMM_HIP_CHECK(hipEventRecord(c.ev_cls, cst));
+        HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln1_g, w.ln1_b, a, R, D, 1e-6f, st));
         if (g_enc_cls_fork) HMM_HIP_CHECK(hipStreamWaitEvent(st, c.ev_cls, 0));
         HMM_TRY(qkv_attention_bf16(a, w.qkv_w, w.qkv_b, hc, big, n_img, st));
         HMM_TRY(gemm_bf16(big, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, c.tile, st));
@@ -502,14 +468,14 @@ static int chain_block(hmm_encoder* e, const Chain& c, int i) {
         HMM_TRY(attention_bf16(big, a, n_img, T, e->heads, D / e->heads, w.bias_k, w.bias_v, st, text));
         if (c.sk_mode == 1 && g_enc_splitk_out > 1) {
             HMM_TRY(gemm_bf16_splitk(a, w.out_w, part, R, D, D, g_enc_splitk_out, -1, st));
-            HMM_TRY(launch_layernorm_reduce_bf16(x, x, part, part_stride, g_enc_splitk_out, 1, w.out_b, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
+            HMM_TRY(launch_layernorm_reduce_bf16(x, part, part_stride, g_enc_splitk_out, w.out_b, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
         } else {
             HMM_TRY(gemm_bf16(a, w.out_w, w.out_b, x, R, D, D, HMM_EPI_BIAS_RESID_F32, c.tile, st));
             HMM_TRY(launch_layernorm_bf16(x, (size_t)D, w.ln2_g, w.ln2_b, a, R, D, 1e-6f, st));
         }
         HMM_TRY(gemm_bf16(a, w.fc1_w, w.fc1_b, big, R, e->mlp, D, HMM_EPI_BIAS_GELU_BF16, c.tile, st));
         if (c.sk_mode && n_splits > 1 && i + 1 < e->depth) {        // the next block's norm_1 reduces (text: the last block has none)
-            HMM_TRY(gemm_bf16_splitk(big, w.fc2_w, part, R, D, e->mlp, n_splits, c.sk_mode == 2 ? HMM_GEMM_TILE_256x256_PP : -1, st));
+            HMM_TRY(gemm_bf16_splitk(big, w.fc2_w, part, R, D, e->mlp, n_splits, -1, st));
             c.pending_bias = w.fc2_b;
         } else {
             HMM_TRY(gemm_bf16(big, w.fc2_w, w.fc2_b, x, R, D, e->mlp, HMM_EPI_BIAS_RESID_F32, c.tile, st));
@@ -579,8 +545,7 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
     // ring) + the attention kernel are faster (1 frame: 3.85 -> 2.60 ms; tools/fused_small_probe.py).  Same bits either way.
     const bool fuse = e->tower != HMM_TOWER_TEXT &&
                       batch * e->clips >= (e->tower == HMM_TOWER_VISION ? g_enc_fused_min_vision : g_enc_fused_min_audio);
-    int sk = splitk_mode(e, batch);
-    if (sk == 1 && fuse) sk = 0;                      // (cannot happen with the shipped limits: the few-row regime ends below the fused one)
+    const int sk = fuse ? 0 : splitk_mode(e, batch);  // (the few-row regime ends far below the fused one)
     Chain chains[2];
     int n_chains = 1;
     int b0 = split_point(e, batch);
@@ -592,13 +557,13 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
         if (cap != hipStreamCaptureStatusNone) b0 = 0;
     }
     if (b0 == 0) {
-        chains[0] = Chain{input_dev, out_dev, ws, ws_plan(e, batch, sk), st, batch, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile, fuse, sk, nullptr, 0};
+        chains[0] = Chain{input_dev, out_dev, ws, ws_plan(e, batch, sk), st, batch, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile, fuse, sk, nullptr};
     } else {
         const WsPlan p0 = ws_plan(e, b0, sk);
-        chains[0] = Chain{input_dev, out_dev, ws, p0, st, b0, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile, fuse, sk, nullptr, 0};
+        chains[0] = Chain{input_dev, out_dev, ws, p0, st, b0, e->cls_stream[0], e->ev_x[0], e->ev_cls[0], tile, fuse, sk, nullptr};
         chains[1] = Chain{static_cast<const char*>(input_dev) + (size_t)b0 * in_bytes_per_sample, out_dev + (size_t)b0 * HMM_FEATURE_DIM,
                           ws + p0.total, ws_plan(e, batch - b0, sk), e->side_stream, batch - b0,
-                          e->cls_stream[1], e->ev_x[1], e->ev_cls[1], tile, fuse, sk, nullptr, 0};
+                          e->cls_stream[1], e->ev_x[1], e->ev_cls[1], tile, fuse, sk, nullptr};
         n_chains = 2;
         HMM_HIP_CHECK(hipEventRecord(e->ev_fork, st));                       // fork
         HMM_HIP_CHECK(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));

@@ -15,8 +15,8 @@ int gemm_set_small_tiles(int tiles);
 // order by launch_layernorm_reduce_bf16 -- the LayerNorm that follows every residual GEMM -- together with the bias and the
 // residual.  tile < 0: by shape among the ring geometries.
 int gemm_bf16_splitk(const bf16_t* A, const bf16_t* W, float* part, int M, int N, int K, int splits, int tile, hipStream_t st);
-int launch_layernorm_reduce_bf16(const float* x_in, float* x_out, const float* part, size_t part_stride, int splits, int row_step,
-                                 const float* bias, const float* g, const float* b, bf16_t* y, int rows, int D, float eps, hipStream_t st);
+int launch_layernorm_reduce_bf16(float* x, const float* part, size_t part_stride, int splits, const float* bias,
+                                 const float* g, const float* b, bf16_t* y, int rows, int D, float eps, hipStream_t st);
 
 int launch_layernorm_bf16(const float* x, size_t in_stride, const float* g, const float* b, bf16_t* y,
                           int rows, int D, float eps, hipStream_t st);

@@ -65,25 +65,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void laye
     }
 }
 
-// The consumer side of a split-K residual GEMM (gemm_bf16_splitk): x_out[r] = ((p_0[r] + p_1[r] + ... + p_{S-1}[r]) + bias) + x_in[r]
-// -- the slabs in split order, then the bias, then the residual, the non-split epilogue's (accumulator + bias) + x -- and
-// y_bf16[i] = LN(x_out[r]), r = i * row_step (row_step = 1: every row; row_step = T: token 0 of every sample, the cls-row
-// projection of the fused attention path).  x_out may be x_in (in place), another buffer, or null (nothing written: a second
-// reader of rows that another launch updates out of place).  A row's bits depend on S only, not on the launch.
+// The consumer side of a split-K residual GEMM (gemm_bf16_splitk): x[r] = ((p_0[r] + p_1[r] + ... + p_{S-1}[r]) + bias) + x[r]
+// -- the slabs in split order, then the bias, then the residual, the non-split epilogue's (accumulator + bias) + x -- written
+// back to the fp32 stream, and y_bf16[r] = LN(x[r]).  A row's bits depend on S only, not on the launch.
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_reduce_bf16_kernel(const float* x_in, float* x_out, const float* __restrict__ part,
-                                                                    size_t part_stride, int splits, int row_step,
+__global__ __launch_bounds__(256) void layernorm_reduce_bf16_kernel(float* __restrict__ x, const float* __restrict__ part,
+                                                                    size_t part_stride, int splits,
                                                                     const float* __restrict__ bias,
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta,
                                                                     bf16_t* __restrict__ y, int rows, float eps) {
     constexpr int D = 256 * NV;
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= rows) return;
-    const size_t row = (size_t)i * row_step;
-    const float* xr = x_in + row * D;
-    const float* pr = part + row * D;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* xr = x + (size_t)row * D;
+    const float* pr = part + (size_t)row * D;
     float4 v[NV], acc[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -102,10 +99,10 @@ __global__ __launch_bounds__(256) void layernorm_reduce_bf16_kernel(const float*
     for (int j = 0; j < NV; ++j) {
         const float4 b = *reinterpret_cast<const float4*>(bias + 4 * (64 * j + lane));
         v[j] = make_float4((acc[j].x + b.x) + v[j].x, (acc[j].y + b.y) + v[j].y, (acc[j].z + b.z) + v[j].z, (acc[j].w + b.w) + v[j].w);
-        if (x_out != nullptr) *reinterpret_cast<float4*>(x_out + row * D + 4 * (64 * j + lane)) = v[j];
+        *reinterpret_cast<float4*>(xr + 4 * (64 * j + lane)) = v[j];
     }
     row_layernorm<NV>(v, gamma, beta, eps, lane);
-    bf16_t* dst = y + (size_t)i * D;
+    bf16_t* dst = y + (size_t)row * D;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         bf16x4 o = {(bf16_t)v[j].x, (bf16_t)v[j].y, (bf16_t)v[j].z, (bf16_t)v[j].w};
@@ -321,15 +318,15 @@ int launch_layernorm_bf16(const float* x, size_t in_stride, const float* g, cons
     return HMM_OK;
 }
 
-int launch_layernorm_reduce_bf16(const float* x_in, float* x_out, const float* part, size_t part_stride, int splits, int row_step,
-                                 const float* bias, const float* g, const float* b, bf16_t* y, int rows, int D, float eps, hipStream_t st) {
+int launch_layernorm_reduce_bf16(float* x, const float* part, size_t part_stride, int splits, const float* bias,
+                                 const float* g, const float* b, bf16_t* y, int rows, int D, float eps, hipStream_t st) {
     HMM_REQUIRE(D == 768 || D == 1024 || D == 1280, HMM_E_INVALID, "layernorm_reduce: D must be 768, 1024 or 1280, got %d", D);
-    HMM_REQUIRE(splits >= 1 && splits <= 8 && row_step >= 1, HMM_E_INVALID, "layernorm_reduce: splits=%d row_step=%d", splits, row_step);
+    HMM_REQUIRE(splits >= 1 && splits <= 8, HMM_E_INVALID, "layernorm_reduce: splits=%d", splits);
     if (rows <= 0) return HMM_OK;
     const int blocks = (rows + 3) / 4;
-    if (D == 768)       layernorm_reduce_bf16_kernel<3><<<blocks, 256, 0, st>>>(x_in, x_out, part, part_stride, splits, row_step, bias, g, b, y, rows, eps);
-    else if (D == 1024) layernorm_reduce_bf16_kernel<4><<<blocks, 256, 0, st>>>(x_in, x_out, part, part_stride, splits, row_step, bias, g, b, y, rows, eps);
-    else                layernorm_reduce_bf16_kernel<5><<<blocks, 256, 0, st>>>(x_in, x_out, part, part_stride, splits, row_step, bias, g, b, y, rows, eps);
+    if (D == 768)       layernorm_reduce_bf16_kernel<3><<<blocks, 256, 0, st>>>(x, part, part_stride, splits, bias, g, b, y, rows, eps);
+    else if (D == 1024) layernorm_reduce_bf16_kernel<4><<<blocks, 256, 0, st>>>(x, part, part_stride, splits, bias, g, b, y, rows, eps);
+    else                layernorm_reduce_bf16_kernel<5><<<blocks, 256, 0, st>>>(x, part, part_stride, splits, bias, g, b, y, rows, eps);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
@@ -421,6 +418,6 @@ extern "C" int hmm_op_layernorm_reduce_bf16(float* x_dev, const float* part_dev,
                                             const float* gamma_dev, const float* beta_dev, uint16_t* y_dev, int rows, int D,
                                             float eps, hmm_stream_t stream) {
     HMM_REQUIRE(x_dev && part_dev && bias_dev && gamma_dev && beta_dev && y_dev, HMM_E_INVALID, "layernorm_reduce: null pointer");
-    return launch_layernorm_reduce_bf16(x_dev, x_dev, part_dev, (size_t)rows * D, splits, 1, bias_dev, gamma_dev, beta_dev,
+    return launch_layernorm_reduce_bf16(x_dev, part_dev, (size_t)rows * D, splits, bias_dev, gamma_dev, beta_dev,
                                         reinterpret_cast<bf16_t*>(y_dev), rows, D, eps, static_cast<hipStream_t>(stream));
 }

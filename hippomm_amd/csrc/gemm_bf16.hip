@@ -632,65 +632,6 @@ HMM_TUNABLE(int, g_gemm_col_major, 0)
 static thread_local int t_gemm_tail_launch = 0;       // the peeled tail of a big launch keeps the row-major list (set by gemm_bf16)
 static thread_local int t_gemm_splits = 1;            // > 1: the next launch_gemm is a split-K launch (set by gemm_bf16_splitk)
 
-// Split-K on the ping-pong tile, for the N = 1280 GEMM with the long K of a MID-size forward (8 ... 48 frames): fc2 of a 16-frame
-// chain is 85 tiles of 256 x 256 walking 80 K-tiles each -- a third of the chip busy for ~110 us.  `splits` workgroups per tile
-// take K-pair ranges of near-equal length (40 pairs over 3 splits: 14 / 13 / 13; the ranges depend on (K, splits) only) and
-// store their fp32 accumulators, no bias, to slab[split][M][N]; launch_layernorm_reduce_bf16 adds the slabs in split order.
-__global__ __launch_bounds__(512) void gemm_bf16_pp_splitk_kernel(
-    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, float* __restrict__ part, int M, int N, int K,
-    int tiles_n, int tiles, int splits) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int nb = gridDim.x, bid = blockIdx.x;
-    const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int split = swz / tiles, tl = swz - split * tiles;
-    const int m0 = (tl / tiles_n) * 256, n0 = (tl % tiles_n) * 256;
-    const int pairs = K >> 7, base = pairs / splits, rem = pairs % splits;            // K-tile pairs: the first `rem` splits take one more
-    const int p0 = split * base + (split < rem ? split : rem), np = base + (split < rem ? 1 : 0);
-
-    PPSources src;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int lr = (wave + 8 * j) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((lr >> 1) & 7);
-        const int arow = (lr & 63) + (lr >> 6) * 128;
-        int g0 = m0 + arow, g1 = m0 + arow + 64;
-        g0 = g0 < M ? g0 : M - 1;
-        g1 = g1 < M ? g1 : M - 1;
-        src.alo[j] = g0 * K + c * 8;
-        src.ahi[j] = g1 * K + c * 8;
-        const int bcol = (lr >> 5) * 64 + (lr & 31);
-        src.blo[j] = (n0 + bcol) * K + c * 8;
-        src.bhi[j] = (n0 + bcol + 32) * K + c * 8;
-    }
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    pp_mainloop(A + (size_t)p0 * 128, W + (size_t)p0 * 128, src, 2 * np, smem, lane, wave, acc);
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    gemm_epilogue_lds<HMM_EPI_F32>(acc, nullptr, part + (size_t)split * M * N, M, N, m0 + wm * 128, n0 + wn * 64,
-                                   smem + wave * kEpiSlab, lane_e);
-}
-
-static int launch_gemm_pp_splitk(const bf16_t* A, const bf16_t* W, float* part, int M, int N, int K, int splits, hipStream_t st) {
-    constexpr int LDS = 8 * kEpiSlab > 2 * 4 * 16384 ? 8 * kEpiSlab : 2 * 4 * 16384;
-    HMM_REQUIRE(N % 256 == 0 && K % 128 == 0 && (K >> 7) >= splits, HMM_E_INVALID,
-                "gemm_splitk: the ping-pong tile needs N %% 256 == 0, K %% 128 == 0 and K / 128 >= splits (N=%d K=%d splits=%d)", N, K, splits);
-    HMM_REQUIRE((size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31), HMM_E_INVALID, "gemm_splitk: operand too large for 32-bit staging offsets");
-    const int tiles_m = (M + 255) / 256, tiles_n = N / 256, tiles = tiles_m * tiles_n;
-    auto kern = gemm_bf16_pp_splitk_kernel;
-    HMM_ENSURE_DYN_LDS(kern, LDS);
-    kern<<<tiles * splits, 512, LDS, st>>>(A, W, part, M, N, K, tiles_n, tiles, splits);
-    HMM_LAUNCH_CHECK();
-    return HMM_OK;
-}
-
 template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2, int KSUB = 1>
 static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                        hipStream_t st) {
@@ -873,6 +814,7 @@ int gemm_set_small_tiles(int tiles) {
     t_gemm_small_tiles = tiles;
     return prev;
 }
+HMM_TUNABLE(int, g_gemm_rect, 1)          // probe build: 0 = never the 128 x 64 ring tiles (A/B)
 HMM_TUNABLE(int, g_gemm_tail_64, 128)      // the peeled last row tile of a big launch uses 64x64 tiles up to this many of them
 static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                                  int epi, hipStream_t st, bool tail = false) {
@@ -888,6 +830,14 @@ static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* 
     }
     if (g_gemm_small_64 &&
         (long)((M + 63) / 64) * (N / 64) <= (tail ? g_gemm_tail_64 : g_gemm_small_64)) {
+        // a few hundred rows with more 64 x 64 tiles than CUs, but at most one 128 x 64 tile per CU: nobody runs two workgroups one
+        // after (or beside) the other -- one frame's qkv / fc1 (300 / 400 tiles -> 180 / 240) 13.9 -> 12.1 us / 15.0 -> 13.0 us
+        // alone with cold weights (profiles/r5_rect_tile_probe.json), one frame's forward 2.24 -> 2.12 ms, four questions
+        // 1.234 -> 1.224.  Beyond ~300 rows it loses in the forwards (one / two audio segments +1 / +10 %, three frames +1 %,
+        // profiles/r5_rect_forward.json: the 128-row tile's K-step is 0.47 us against 0.29, which only pays while it halves the
+        // workgroups per CU of a SHORT K walk), hence the row limit.
+        if (g_gemm_rect && !tail && M <= 320 && (long)((M + 63) / 64) * (N / 64) > kNumCU && (long)((M + 127) / 128) * (N / 64) <= kNumCU)
+            return launch_gemm_ring_rect_epi<128, 64>(A, W, bias, C, M, N, K, epi, st);
         // at most one 64x64 tile per CU: the deep-K ring (96 KiB, one workgroup per CU anyway) -- one frame's fc2 24.5 -> 21.9 us,
         // its out-proj 8.6 -> 8.0 (cold weights, tools/deepk_probe.py); with more tiles than CUs two plain-ring workgroups per CU win
         if (g_gemm_deepk && !tail && epi <= HMM_EPI_F32 && (K >> 6) % 2 == 0 && K >= 1024 && (long)((M + 63) / 64) * (N / 64) <= kNumCU)
@@ -976,11 +926,9 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
 HMM_TUNABLE(int, g_gemm_splitk_tile, -1)     // probe build: force a ring geometry for the split launches
 int gemm_bf16_splitk(const bf16_t* A, const bf16_t* W, float* part, int M, int N, int K, int splits, int tile, hipStream_t st) {
     HMM_REQUIRE(A && W && part, HMM_E_INVALID, "gemm_splitk: null pointer");
-    HMM_REQUIRE(M >= 1 && N >= 128 && N % 128 == 0 && splits >= 1 && splits <= 8, HMM_E_INVALID,
+    HMM_REQUIRE(M >= 1 && N >= 128 && N % 128 == 0 && splits >= 1 && splits <= 8 && K % (64 * splits) == 0, HMM_E_INVALID,
                 "gemm_splitk: unsupported shape M=%d N=%d K=%d splits=%d", M, N, K, splits);
     if (g_gemm_splitk_tile >= 0) tile = g_gemm_splitk_tile;
-    if (tile == HMM_GEMM_TILE_256x256_PP) return launch_gemm_pp_splitk(A, W, part, M, N, K, splits, st);   // near-equal K ranges
-    HMM_REQUIRE(K % (64 * splits) == 0, HMM_E_INVALID, "gemm_splitk: K = %d is not a multiple of 64 x %d splits", K, splits);
     const int k_len = K / splits;
     if (tile < 0) {
         // by the number of 64 x 64 workgroups (profiles/r5_splitk_probe.json, cold weights): under half a chip of them, 32 x 32

@@ -294,36 +294,6 @@ def test_gemm_split_k_partials_and_the_layernorm_that_reduces_them(M, N, K, spli
     assert torch.equal(x1, x2) and torch.equal(y1, y2)
 
 
-@pytest.mark.parametrize("M,N,K,splits", [(4112, 1280, 5120, 3), (2056, 1280, 5120, 3), (300, 1280, 5120, 2), (700, 768, 3072, 4),
-                                           (8224, 1280, 1280, 3)])
-def test_gemm_split_k_on_the_ping_pong_tile(M, N, K, splits):
-    """Mid-size forwards (8-48 frames) run fc2 as split-K on the 256x256 ping-pong tile: K / 128 K-tile pairs dealt to the splits
-    in near-equal runs (40 pairs over 3 splits: 14 / 13 / 13).  Every slab against a torch fp32 product over the same K range;
-    with equal ranges (K / 128 divisible by the splits) bitwise equal to the ring geometries' slabs; rows past M untouched."""
-    L, lib = _lib()
-    g = torch.Generator().manual_seed(M + N + K + splits)
-    a = _bf16(torch.randn(M, K, generator=g))
-    w = _bf16(torch.randn(N, K, generator=g) * 0.05)
-    ad, wd = a.cuda(), w.cuda()
-    part = torch.full((splits * M + 2, N), float("nan"), device="cuda")
-    L.check(lib.hmm_op_gemm_bf16_splitk(ad.data_ptr(), wd.data_ptr(), part.data_ptr(), M, N, K, splits, 3, L.stream_ptr()), "pp splitk")
-    assert torch.isnan(part[splits * M:]).all()
-    got = part[:splits * M].reshape(splits, M, N)
-    pairs, base, rem = K // 128, (K // 128) // splits, (K // 128) % splits
-    k0 = 0
-    for s_ in range(splits):
-        n = (base + (1 if s_ < rem else 0)) * 128
-        want = a[:, k0:k0 + n].float().cuda() @ w[:, k0:k0 + n].float().cuda().T
-        err = (got[s_] - want).abs().max().item()
-        assert err <= 2e-4 * max(1.0, want.abs().max().item()), (s_, err)
-        k0 += n
-    assert k0 == K
-    if pairs % splits == 0:
-        ring = torch.empty(splits, M, N, device="cuda")
-        L.check(lib.hmm_op_gemm_bf16_splitk(ad.data_ptr(), wd.data_ptr(), ring.data_ptr(), M, N, K, splits, 6, L.stream_ptr()), "ring splitk")
-        assert torch.equal(ring, got), "ping-pong slabs differ from the 128x128 ring's over the same K ranges"
-
-
 def test_gemm_split_k_argument_errors():
     L, lib = _lib()
     a = torch.zeros(64, 1024, dtype=torch.bfloat16, device="cuda")
@@ -332,9 +302,7 @@ def test_gemm_split_k_argument_errors():
     st = L.stream_ptr()
     assert lib.hmm_op_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), part.data_ptr(), 64, 1024, 1024, 3, -1, st) == -1    # 1024 / 3
     assert lib.hmm_op_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), part.data_ptr(), 64, 1024, 1024, 9, -1, st) == -1
-    assert lib.hmm_op_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), part.data_ptr(), 64, 1024, 1024, 2, 2, st) == -1     # no such split geometry
-    assert lib.hmm_op_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), part.data_ptr(), 64, 1024, 1024, 8, 3, st) == 0      # ping-pong: 8 pairs over 8 splits
-    assert lib.hmm_op_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), part.data_ptr(), 64, 1024, 512, 5, 3, st) == -1      # 4 pairs < 5 splits
+    assert lib.hmm_op_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), part.data_ptr(), 64, 1024, 1024, 2, 3, st) == -1     # ping-pong tile: no split launch
     assert lib.hmm_op_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), part.data_ptr(), 64, 1024, 1024, 8, 10, st) == -1    # K/8 = 128: no K4 ring
     assert lib.hmm_op_gemm_bf16_splitk(None, w.data_ptr(), part.data_ptr(), 64, 1024, 1024, 2, -1, st) == -1
     assert lib.hmm_op_layernorm_reduce_bf16(part.data_ptr(), part.data_ptr(), 0, part.data_ptr(), part.data_ptr(), part.data_ptr(),

@@ -26,6 +26,7 @@ def set_fc2(v):
     _set_fc2_t(v)
 set_out = setter(lib, "g_enc_splitk_out")
 set_sktile = setter(lib, "g_gemm_splitk_tile")
+set_rect = setter(lib, "g_gemm_rect")
 EPI = {"bias": 0, "gelu": 1, "resid": 2}
 TILE = {"auto": -1, "ring128": 6, "ring64": 7, "ring32": 8, "ring32_k2": 9, "ring32_k4": 10, "ring64_k2": 11}
 out_path = next((a for a in sys.argv[1:] if not a.startswith("--")), None)
@@ -135,7 +136,7 @@ def wall_ms(fn, iters=30):
 
 def part_b():
     from hippomm_amd.encoder import HipTower, synthetic_state_dict
-    for kind, batches in (("text", (1, 4, 5, 6, 7, 8, 9)),):
+    for kind, batches in (("text", (1, 4)), ("vision", (1, 2, 3)), ("audio", (1, 2))):
         sd = synthetic_state_dict((kind,), seed=99)
         tower = HipTower(kind, sd)
         del sd
@@ -149,13 +150,18 @@ def part_b():
                 x = torch.randn(B, 3, 224, 224, device="cuda")
             rec = {"tower": kind, "batch": B}
             base = None
-            variants = [("r4", 0, 0, 2, 1), ("sk_2_1", 0, 700, 2, 1), ("sk_4_1", 0, 700, 4, 1), ("r4_again", 0, 0, 2, 1),
-                        ("sk_2_1_again", 0, 700, 2, 1), ("sk_4_1_again", 0, 700, 4, 1)]
+            variants = [("r4", 0, 0, 2, 1), ("product", 0, 700, -1, 1), ("product_no_rect", 0, 700, -2, 1), ("r4_again", 0, 0, 2, 1),
+                        ("product_again", 0, 700, -1, 1), ("product_no_rect_again", 0, 700, -2, 1)]
             for tag, col, rows, fc2, outp in variants:
                 set_col(col)
                 set_rows(rows)
-                set_rows_v(rows)
-                set_fc2(fc2)
+                set_rows_v(300 if rows else 0)
+                set_rect(0 if fc2 == -2 or tag.startswith("r4") else 1)
+                if fc2 > 0:
+                    set_fc2(fc2)
+                else:                                   # the product's per-tower split factors
+                    _set_fc2_va(2)
+                    _set_fc2_t(4)
                 set_out(outp)
                 out = torch.empty(B, 1024, device="cuda")
                 try:
