@@ -92,7 +92,10 @@ int    hmm_topk_merge_keys(const uint64_t* keys_dev /* [n_shards][k] */, int n_s
  * complete (a store of thousands of near-ties) the exact scan runs instead, inside the same call, decided on the device.
  * k > 64 or fewer than 16384 rows: the call IS hmm_cosine_topk.  stats_out_dev (may be null) int32[2]: candidates re-scored and
  * saturated block lists of the last call (-1, -1 when the prefilter was not used); a non-zero second entry or more than 1024
- * candidates means the exact scan answered. */
+ * candidates means the exact scan answered.
+ * Precondition of the bit identity: every row's squared norm is finite and non-zero in fp32 (unit-scale embeddings are).  A row
+ * whose norm overflows or underflows gets a NaN shadow row, which ranks first here, while hmm_cosine_topk gives it 0 or +-inf.
+ * The shadow is a snapshot of the rows it was built from: rebuild it after the rows change. */
 size_t hmm_shadow_store_bytes(int64_t n_rows);
 int    hmm_shadow_store_build(const float* store_dev, int64_t n_rows, int dim, void* shadow_dev, size_t shadow_bytes,
                               hmm_stream_t stream);
