@@ -269,6 +269,7 @@ class _StoreCache:
         store = FeatureStore(b)
         size = store.rows.numel() * 4
         with self._lock:
+            self._drop(key)                      # another thread may have inserted the same array while this one was uploading
             while self.entries and self.bytes + size > self.max_bytes:
                 self._drop(next(iter(self.entries)))
             # the weak reference's callback releases the HBM copy when the host array dies

@@ -249,3 +249,32 @@ def test_feature_store_with_shadow_serves_the_drop_in_call_identically():
             i0, s0 = top_k_cosine_similarity(q, plain, k)
             i1, s1 = top_k_cosine_similarity(q, shadowed, k)
             assert i0.tolist() == i1.tolist() and s0.dtype == s1.dtype and s0.tobytes() == s1.tobytes()
+
+
+def test_shadow_follows_in_place_updates_of_the_rows():
+    """The bf16 shadow is a snapshot of the rows (round-4 advisor finding: a stale shadow silently drops true top-k rows).  An
+    in-place update through torch moves the tensor's version counter and the next prefiltered search rebuilds the shadow;
+    `invalidate_shadow()` / `build_shadow(force=True)` cover writes torch does not see."""
+    from hippomm_amd.vector_ops import FeatureStore
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rows = torch.randn(40000, 1024, generator=g, device="cuda")
+    q = torch.randn(1024, generator=g, device="cuda")
+    store = FeatureStore(rows, shadow=True)                    # aliases `rows` (fp32, contiguous, already on the device)
+    assert store.rows.data_ptr() == rows.data_ptr()
+    i0, s0 = store.search_device(q, 8)
+    # plant a perfect match in a row that was nowhere near the top: the exact scan and the shadow path must both find it
+    target = int((torch.arange(40000, device="cuda")[~torch.isin(torch.arange(40000, device="cuda"), i0)])[12345].item())
+    rows[target] = q * 3.0                                     # in place, through torch: version counter moves
+    i1, s1 = store.search_device(q, 8)                         # use_shadow=True -> the prefilter path, shadow rebuilt first
+    exact = FeatureStore(rows)
+    ie, se = exact.search_device(q, 8)
+    assert int(i1[0].item()) == target and torch.equal(i1, ie) and torch.equal(s1.view(torch.int32), se.view(torch.int32))
+    before = store._shadow.clone()
+    store.build_shadow()                                       # nothing changed since: no rebuild
+    assert torch.equal(store._shadow, before)
+    store.build_shadow(force=True)
+    assert torch.equal(store._shadow, before)                  # same rows -> same shadow bits
+    store.invalidate_shadow()
+    assert store._shadow is None
+    i2, s2 = store.search_device(q, 8)
+    assert torch.equal(i2, ie) and torch.equal(s2.view(torch.int32), se.view(torch.int32))
