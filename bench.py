@@ -223,7 +223,7 @@ def event_time_ms(fn, iters, warmup=2, warm_ms=0.0):
     moved behind a read-back and was timed over launches 4-13."""
     for _ in range(warmup):
         fn()
-    if warm_ms > 0:
+    if warm_ms > 0:                      # never for a leg that contains a collective: the number of calls would differ per rank
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         while (time.perf_counter() - t0) * 1e3 < warm_ms:
@@ -782,7 +782,9 @@ def sharded_scan_bench(rank, world, reduce_max, rows_per_gpu=None, strong=True):
         separated = below & above                                # a rank is pinned only when BOTH neighbours are clear of it
         ok = bool(idx.numel() == SCAN_K and torch.equal(idx[separated], want[:SCAN_K][separated]))
         dist.barrier()
-        ms = reduce_max(event_time_ms(query, 50, warmup=3, warm_ms=SCAN_WARM_MS))
+        # steady state by COUNT, not by time: `query` holds a collective, and a time-based warm-up would let the ranks leave it
+        # after different numbers of calls -- mismatched all-gathers, i.e. a hang
+        ms = reduce_max(event_time_ms(query, 50, warmup=80))
         total = float(n_local) * world * 4096.0
         out[tag] = {"rows_per_gpu": n_local, "ms_per_query": round(ms, 4), "GBps_all_gpus": round(total / ms / 1e6, 1),
                     "frac_of_n_gpus_x_8TBps": round(total / ms / 1e6 / (PEAK_HBM_GBS * world), 4),
