@@ -780,10 +780,10 @@ static int launch_gemm_ringk_epi(const bf16_t* A, const bf16_t* W, const float* 
 // its K walk times the workgroups a CU has to run one after (or beside) the other.  One frame's qkv GEMM is 300 tiles of 64 x 64
 // on 256 CUs -- 44 CUs run two workgroups and the launch takes their time, 13.3 us; as 128 x 64 tiles it is 180 workgroups, one per
 // CU, and the tile's 16 MFMAs per wave and K-tile hide the ring's latencies better than the 8 of a 64 x 64 tile.
-template <int BM, int BN>
+template <int BM, int BN, int WM = 2, int WN = 2>
 static int launch_gemm_ring_rect_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                                      int epi, hipStream_t st) {
-#define HMM_CALL(E) launch_gemm<BM, BN, 2, 2, E, 4>(A, W, bias, C, M, N, K, st)
+#define HMM_CALL(E) launch_gemm<BM, BN, WM, WN, E, 4>(A, W, bias, C, M, N, K, st)
     switch (epi) {
         case HMM_EPI_BIAS_BF16:      return HMM_CALL(HMM_EPI_BIAS_BF16);
         case HMM_EPI_BIAS_GELU_BF16: return HMM_CALL(HMM_EPI_BIAS_GELU_BF16);
@@ -800,6 +800,17 @@ static int launch_gemm_ring128_epi(const bf16_t* A, const bf16_t* W, const float
 #define HMM_CALL(E) launch_gemm<128, 128, 2, 2, E, 4>(A, W, bias, C, M, N, K, st)
     HMM_EPI_SWITCH(HMM_CALL)
 #undef HMM_CALL
+}
+
+// What the dispatcher uses where it says "128 x 128 ring" / "128 x 64 ring": the EIGHT-wave instantiations (wave tiles 64 x 32 /
+// 32 x 32, two waves per SIMD): one wave's LDS reads and DMA issue run under its partner's MFMAs.  Alone with cold weights
+// (profiles/r5_rect_tile_probe2.json) 128 x 128: 17.1 -> 15.2 us (one frame's qkv), 13.3 -> 11.9 (one audio segment's fc1),
+// 53.4 -> 46.8 (eight frames' fc2); 128 x 64: 12.2 -> 11.5, 13.0 -> 11.9.  Same MFMA sequence per output element: same bits.
+HMM_TUNABLE(int, g_gemm_ring8, 1)          // probe build: 0 = the four-wave instantiations (A/B)
+static int launch_gemm_ring128_auto_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
+                                        int epi, hipStream_t st) {
+    return g_gemm_ring8 ? launch_gemm_ring_rect_epi<128, 128, 2, 4>(A, W, bias, C, M, N, K, epi, st)
+                        : launch_gemm_ring128_epi(A, W, bias, C, M, N, K, epi, st);
 }
 
 // Launches of few tiles (small batches, cls rows, the head, the peeled last row tile of the big launches): a workgroup is alone
@@ -837,14 +848,15 @@ static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* 
         // profiles/r5_rect_forward.json: the 128-row tile's K-step is 0.47 us against 0.29, which only pays while it halves the
         // workgroups per CU of a SHORT K walk), hence the row limit.
         if (g_gemm_rect && !tail && M <= 320 && (long)((M + 63) / 64) * (N / 64) > kNumCU && (long)((M + 127) / 128) * (N / 64) <= kNumCU)
-            return launch_gemm_ring_rect_epi<128, 64>(A, W, bias, C, M, N, K, epi, st);
+            return g_gemm_ring8 ? launch_gemm_ring_rect_epi<128, 64, 4, 2>(A, W, bias, C, M, N, K, epi, st)
+                                : launch_gemm_ring_rect_epi<128, 64>(A, W, bias, C, M, N, K, epi, st);
         // at most one 64x64 tile per CU: the deep-K ring (96 KiB, one workgroup per CU anyway) -- one frame's fc2 24.5 -> 21.9 us,
         // its out-proj 8.6 -> 8.0 (cold weights, tools/deepk_probe.py); with more tiles than CUs two plain-ring workgroups per CU win
         if (g_gemm_deepk && !tail && epi <= HMM_EPI_F32 && (K >> 6) % 2 == 0 && K >= 1024 && (long)((M + 63) / 64) * (N / 64) <= kNumCU)
             return launch_gemm_ringk_epi<64, 3, 2>(A, W, bias, C, M, N, K, epi, st);
         return launch_gemm_ring64_epi(A, W, bias, C, M, N, K, epi, st);
     }
-    return launch_gemm_ring128_epi(A, W, bias, C, M, N, K, epi, st);
+    return launch_gemm_ring128_auto_epi(A, W, bias, C, M, N, K, epi, st);
 }
 
 static int launch_gemm_pp_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
@@ -909,6 +921,8 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         case HMM_GEMM_TILE_32x32_RING_K4: return launch_gemm_ringk_epi<32, 4, 4>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_128x64_RING:   return launch_gemm_ring_rect_epi<128, 64>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_64x128_RING:   return launch_gemm_ring_rect_epi<64, 128>(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_128x128_RING8: return launch_gemm_ring_rect_epi<128, 128, 2, 4>(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_128x64_RING8:  return launch_gemm_ring_rect_epi<128, 64, 4, 2>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_256x256_PP: return launch_gemm_pp_epi(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_128x128:    return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_256x128:    return launch_gemm_epi<256, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);

@@ -64,7 +64,7 @@ def test_gemm_epilogues_bitwise_equal_across_tile_geometries():
     for epi, dtype in ((EPI_BIAS_RESID_F32, torch.float32), (EPI_BIAS_GELU_BF16, torch.bfloat16), (EPI_BIAS_BF16, torch.bfloat16),
                        (EPI_F32, torch.float32)):
         outs = []
-        for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
+        for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
             c = c0.clone().to(dtype)
             L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K, epi, variant,
                                               L.stream_ptr()), "gemm")
@@ -88,7 +88,7 @@ def test_gemm_few_rows_sliver_kernel_bitwise_equal_to_the_tiled_kernels(M, N, K)
     for epi, dtype in ((EPI_BIAS_RESID_F32, torch.float32), (EPI_BIAS_GELU_BF16, torch.bfloat16), (EPI_BIAS_BF16, torch.bfloat16),
                        (EPI_F32, torch.float32)):
         outs = []
-        for variant in (0, 5, -1, 6, 7, 8, 9, 10, 11, 12, 13):
+        for variant in (0, 5, -1, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
             c = c0.clone().to(dtype)
             L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K, epi, variant,
                                               L.stream_ptr()), "gemm")
@@ -103,6 +103,8 @@ def test_gemm_few_rows_sliver_kernel_bitwise_equal_to_the_tiled_kernels(M, N, K)
         assert torch.equal(outs[8], outs[0]), f"epilogue {epi}: the 64x64 deep-K ring differs from 128x128 tiles"
         assert torch.equal(outs[9], outs[0]), f"epilogue {epi}: 128x64 tiles behind the ring differ from 128x128 tiles"
         assert torch.equal(outs[10], outs[0]), f"epilogue {epi}: 64x128 tiles behind the ring differ from 128x128 tiles"
+        assert torch.equal(outs[11], outs[0]), f"epilogue {epi}: the eight-wave 128x128 ring differs from 128x128 tiles"
+        assert torch.equal(outs[12], outs[0]), f"epilogue {epi}: the eight-wave 128x64 ring differs from 128x128 tiles"
         assert torch.equal(outs[1][M:], c0[M:].to(dtype)), "rows past M were written"
     want = a.float().cpu() @ w.float().cpu().T + bias.cpu()
     _close_bf16(outs[1][:M], want)                     # the last epilogue of the loop is plain fp32 + bias: a value check on top

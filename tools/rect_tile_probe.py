@@ -11,7 +11,7 @@ from probe_common import load_probe, event_ms
 
 L, lib = load_probe()
 EPI = {"bias": 0, "gelu": 1, "resid": 2}
-TILES = {"db128": 0, "auto": -1, "ring32": 8, "ring64": 7, "ring64_k2": 11, "ring128": 6, "r128x64": 12, "r64x128": 13}
+TILES = {"db128": 0, "auto": -1, "ring32": 8, "ring64": 7, "ring64_k2": 11, "ring128": 6, "r128x64": 12, "r64x128": 13, "r128x128w8": 14, "r128x64w8": 15}
 rows = []
 st = L.stream_ptr()
 SHAPES = [("vision qkv", 3840, 1280, "bias", (257, 514, 1028, 2056)), ("vision fc1", 5120, 1280, "gelu", (257, 514, 1028, 2056)),
@@ -57,7 +57,7 @@ for name, N, K, epi, Ms in SHAPES:
             part = torch.empty(S, M, N, device="cuda")
             pref = None
             for tag, tile in TILES.items():
-                if tag == "db128" or (tag == "ring32" and ((M + 31) // 32) * (N // 32) * S > 4096) or \
+                if tag in ("db128", "r128x128w8", "r128x64w8") or (tag == "ring32" and ((M + 31) // 32) * (N // 32) * S > 4096) or \
                         (tag == "ring64_k2" and (((M + 63) // 64) * (N // 64) * S > 600 or (K // S) % 128)):
                     continue
 
