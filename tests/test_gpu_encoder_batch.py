@@ -233,14 +233,15 @@ def test_regimes_agree_within_the_stated_tolerance():
         del tower
 
 
-@pytest.mark.parametrize("batch,streams", [(6, 2), (70, 1), (70, 2)])
+@pytest.mark.parametrize("batch,streams", [(1, 2), (6, 2), (70, 1), (70, 2)])     # 1 frame: the few-row regime (split-K fc2, depth 3)
 def test_forward_is_graph_capturable(batch, streams):
     """include/hippomm_hip.h: every launch goes to the caller's stream and nothing synchronises or allocates, so a forward
     (including its internal fork / join onto the handle's own streams) can be captured into a HIP graph and replayed."""
     from hippomm_amd.encoder import HipTower
-    spec = ib.reduced(ib.VISION_HUGE, 2)
+    depth = 3 if batch == 1 else 2                      # split-K needs a block behind the split one
+    spec = ib.reduced(ib.VISION_HUGE, depth)
     st = ib.synthetic_state(spec, seed=13, init="rich")
-    tower = HipTower("vision", st, depth=2)
+    tower = HipTower("vision", st, depth=depth)
     tower.set_streams(streams)
     x = _frames(batch, seed=2).cuda()
     out = torch.empty(batch, 1024, device="cuda")
