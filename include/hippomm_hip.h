@@ -185,7 +185,13 @@ int  hmm_encoder_missing_params(hmm_encoder* enc);
 
 size_t hmm_encoder_workspace_bytes(const hmm_encoder* enc, int batch);
 /* input_dev: vision (batch,3,224,224) fp32 | audio (batch,3,1,128,204) fp32 | text (batch,77) int64
- * out_dev:   (batch,1024) fp32 */
+ * out_dev:   (batch,1024) fp32
+ * The kernels are chosen by the size of the call (the reference calls with one question, one audio segment, the frames of a
+ * segment or a 32-frame buffer: hippocampal_memory.py:1180, :1222, :1328, :2173).  A sample's embedding does not depend on the
+ * batch it arrives in WITHIN a regime, bit for bit; there are two: few-row forwards (batch x clips x tokens <= 300 rows for the
+ * vision tower = one frame, <= 700 for audio / text = one segment, up to nine questions), whose fc2 is a deterministic split-K
+ * launch reduced inside the next LayerNorm, and everything larger.  Across the boundary the embeddings agree to 1 - cos ~ 1e-5
+ * (stated tolerance 5e-5). */
 int  hmm_encoder_forward(hmm_encoder* enc, const void* input_dev, int batch, float* out_dev,
                          void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
 /* FLOPs (2 x MAC) of one forward of `batch` samples as the REFERENCE computes it (un-folded patch convolution, every
