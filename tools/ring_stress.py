@@ -24,7 +24,7 @@ for M, N, K in shapes:
     for epi, dtype in ((2, torch.float32), (1, torch.bfloat16)):
         ref = x0.clone().to(dtype)
         L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), ref.data_ptr(), M, N, K, epi, 0, L.stream_ptr()), "ref")
-        for tile in (5, 6, 7, 8, 9, 10, 11, -1):
+        for tile in (5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, -1):     # incl. round 5's 128x64 / 64x128 and eight-wave ring tiles
             if tile in (9, 11) and (K // 64) % 2:
                 continue
             if tile == 10 and (K // 64) % 4:
@@ -41,6 +41,30 @@ for M, N, K in shapes:
             if diff:
                 bad += diff
                 print(f"M={M} N={N} K={K} epi={epi} tile={tile}: {diff} of {REPS} runs differ", flush=True)
+    # round 5: the split-K slabs + the reducing LayerNorm under the same perturbation (bits depend on (K, splits) only)
+    for S in (2, 4):
+        if K % (128 * S) or N not in (768, 1024, 1280):
+            continue
+        gam, bet = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
+        ref_x = ref_y = None
+        for tile in (-1, 6, 7, 8, 11, 12, 13):
+            diff = 0
+            for r in range(REPS // 2):
+                if r % 2 == 0:
+                    with torch.cuda.stream(side):
+                        L.check(lib.hmm_op_gemm_bf16_tile(big_a.data_ptr(), big_w.data_ptr(), big_b.data_ptr(), big_c.data_ptr(), 8192, 5120, 1280, 1, 3,
+                                                          side.cuda_stream), "load")
+                part = torch.empty(S, M, N, device="cuda")
+                x, y = x0.clone(), torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+                L.check(lib.hmm_op_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), part.data_ptr(), M, N, K, S, tile, L.stream_ptr()), "splitk")
+                L.check(lib.hmm_op_layernorm_reduce_bf16(x.data_ptr(), part.data_ptr(), S, bias.data_ptr(), gam.data_ptr(), bet.data_ptr(),
+                                                         y.data_ptr(), M, N, 1e-6, L.stream_ptr()), "ln_reduce")
+                if ref_x is None:
+                    ref_x, ref_y = x.clone(), y.clone()
+                diff += int(not (torch.equal(x, ref_x) and torch.equal(y, ref_y)))
+            if diff:
+                bad += diff
+                print(f"M={M} N={N} K={K} split-K {S} tile={tile}: {diff} of {REPS // 2} runs differ", flush=True)
     torch.cuda.synchronize()
     print(f"M={M} N={N} K={K}: done", flush=True)
 print("ring stress:", "OK" if bad == 0 else f"{bad} MISMATCHES")
