@@ -825,6 +825,7 @@ int gemm_set_small_tiles(int tiles) {
     t_gemm_small_tiles = tiles;
     return prev;
 }
+HMM_TUNABLE(int, g_gemm_small_by_r128, 1) // probe build: 0 = the small-tile decision on the count of 256 x 256 tiles alone (round 4)
 HMM_TUNABLE(int, g_gemm_rect, 1)          // probe build: 0 = never the 128 x 64 ring tiles (A/B)
 HMM_TUNABLE(int, g_gemm_tail_64, 128)      // the peeled last row tile of a big launch uses 64x64 tiles up to this many of them
 static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
@@ -887,8 +888,12 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         // makes the main launch an exact number of rounds.
         const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
         const long tiles = (long)tiles_m * tiles_n;
-        // few 256x256 tiles (cls-only last block, head): 128x128 tiles put 4x more CUs to work
-        if (tiles < t_gemm_small_tiles)
+        // few 256x256 tiles (cls-only last block, head, small and mid-size batches): smaller tiles put more CUs to work.  Also
+        // when the launch is at most ONE 128 x 128 tile per CU: with rows just past a multiple of 256 (12 frames = 12 x 256 + 12
+        // rows) the 256-row count jumps a whole tile row early -- 65 ping-pong tiles for what is 250 ring tiles (24 frames on two
+        // chains 10.50 -> 9.94 ms, profiles/r5_small_by_r128_ab.json)
+        const long r128 = (long)((M + 127) / 128) * (N / 128);
+        if (tiles < t_gemm_small_tiles || (g_gemm_small_by_r128 && r128 <= kNumCU))
             return sliver_ok && sliver_wins(M, N, K, epi) ? launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, st)
                                              : launch_gemm_small_epi(A, W, bias, C, M, N, K, epi, st);
         // peel p <= 2 row tiles when that leaves the main launch with a last round that is full or nearly full (>= 240 of 256

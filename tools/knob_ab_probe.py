@@ -28,7 +28,7 @@ def wall_ms(fn, iters):
 
 
 rows = []
-for kind, batches in (("text", (1, 4, 9, 16)), ("vision", (1, 2, 3, 8, 16, 32, 64, 256)), ("audio", (1, 2, 8, 32))):
+for kind, batches in (("text", (1, 4, 9, 16, 32, 64, 96)), ("vision", (1, 2, 3, 8, 12, 13, 14, 15, 16, 20, 22, 24, 26, 28, 32, 48, 64, 256)), ("audio", (1, 2, 4, 6, 8, 12, 16, 32, 128))):
     tower = HipTower(kind, synthetic_state_dict((kind,), seed=99))
     for B in batches:
         if kind == "text":

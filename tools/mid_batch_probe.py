@@ -1,5 +1,6 @@
 """Mid-size vision batches (16 .. 64 frames): chains (1 / 2) x the tile count below which a launch leaves the 256x256 ping-pong
 kernel for the small-tile kernels.  usage: mid_batch_probe.py"""
+import sys
 import time
 from probe_common import load_probe, setter
 import torch
@@ -21,7 +22,7 @@ def wall_ms(fn, iters=10):
     return (time.perf_counter() - t) / iters * 1e3
 
 
-for B in (16, 20, 24, 28, 32, 40, 48, 56, 64, 96, 128, 256):
+for B in ([int(a) for a in sys.argv[1:]] or (16, 20, 24, 28, 32, 40, 48, 56, 64, 96, 128, 256)):
     torch.manual_seed(B)
     x = torch.randn(B, 3, 224, 224, device="cuda")
     ref = None
@@ -30,7 +31,7 @@ for B in (16, 20, 24, 28, 32, 40, 48, 56, 64, 96, 128, 256):
         set_min(m)
         tower = HipTower("vision", synthetic_state_dict(("vision",), seed=99))
         out = torch.empty(B, 1024, device="cuda")
-        for small in ((128,) if chains == '1ch' else (128, 64)):
+        for small in ((128, 256) if chains == '1ch' else (128, 64, 32)):
             set_small(small)
             ms = wall_ms(lambda: tower.forward_into(x, out))
             if ref is None:
