@@ -359,8 +359,8 @@ extern "C" double hmm_encoder_flops_executed(const hmm_encoder* e, int batch) {
 
 namespace hmm {
 HMM_TUNABLE(int, g_enc_cls_fork, 1)      // probe build: 0 = cls-row projection on the chain's own stream (A/B)
-HMM_TUNABLE(int, g_enc_fused_min_vision, 32) // frames of a forward from which in_proj + attention run as the fused kernel
-HMM_TUNABLE(int, g_enc_fused_min_audio, 6)   // clips (3 per segment) likewise
+HMM_TUNABLE(int, g_enc_fused_min_vision, 48) // frames of a forward from which in_proj + attention run as the fused kernel (round 5, profiles/r5_fused_min_ab2.json: projection GEMM + attention kernel 32 / 36 / 40 / 44 frames -2.3 / -2.2 / -3.6 / -1.3 %, equal at 48, +1 ... +4.6 % from 56 on)
+HMM_TUNABLE(int, g_enc_fused_min_audio, 9)   // clips (3 per segment) likewise: from three segments on (two segments 0.865 -> 0.839 ms unfused, three 0.936 vs 0.998; profiles/r5_fused_min_audio_ab.json)
 HMM_TUNABLE(int, g_enc_mlp_chunk_rows, 0)  // probe build: > 0 = fc1 -> fc2 per chunk of this many token rows, the hidden activation of every chunk in the SAME buffer (round 5's energy experiment: keep it inside the 256-MB Infinity Cache; measured, not kept -- profiles/r5_mlp_chunk_probe.json)
 HMM_TUNABLE(int, g_enc_sliver_rows, 16448) // token rows of a forward (batch x clips x tokens) up to which few-row GEMMs may use the sliver kernel
 

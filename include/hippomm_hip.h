@@ -200,14 +200,15 @@ double hmm_encoder_flops(const hmm_encoder* enc, int batch);
 /* FLOPs this build actually executes for the same forward: temporal taps of the Conv3d folded into one K-padded matrix,
  * and the last block computed for the selected row only (vision / audio: K,V for every token, the rest for token 0). */
 double hmm_encoder_flops_executed(const hmm_encoder* enc, int batch);
-/* n_streams = 2 (default): from 16 frames / 4 audio segments / 64 questions on, a forward runs as two half-batches, the second on a stream owned
+/* n_streams = 2 (default): from 13 frames / 4 audio segments / 64 questions on, a forward runs as two half-batches, the second on a stream owned
  * by the handle (forked from / joined to the caller's stream with events).  n_streams = 1: one chain on the caller's
  * stream only.  Embeddings are bitwise identical either way (tests/test_gpu_encoder_batch.py). */
 int  hmm_encoder_set_streams(hmm_encoder* enc, int n_streams);
 /* Vision and audio towers: on (default) = in_proj and the attention core of a block run as ONE kernel per (sample, head)
  * and the packed qkv matrix never goes through HBM; off = a QKV GEMM followed by the attention kernel.  Embeddings are
  * bitwise identical either way.  No effect on the text tower (77 tokens would fill 30 % of the kernel's 256-row tile).
- * Forwards below 32 frames / 6 clips use the two-kernel path regardless: the fused kernel is 16 (12) workgroups per sample. */
+ * Forwards below 48 frames / 9 clips (three segments) use the two-kernel path regardless: the fused kernel is 16 (12) workgroups
+ * per sample. */
 int  hmm_encoder_set_fused_attention(hmm_encoder* enc, int on);
 
 /* ------------------------------------------------------------------------------------------

@@ -179,7 +179,7 @@ def test_full_depth_audio_batch128_and_text_batch96_bitwise_batch_invariance():
 def _towers_for_regimes():
     from hippomm_amd.encoder import HipTower
     spec = ib.reduced(ib.VISION_HUGE, 3)
-    yield "vision", HipTower("vision", ib.synthetic_state(spec, seed=31, init="rich"), depth=3), _frames(40, seed=12), 1, 2
+    yield "vision", HipTower("vision", ib.synthetic_state(spec, seed=31, init="rich"), depth=3), _frames(52, seed=12), 1, 2
     spec = ib.reduced(ib.AUDIO_HUGE, 3)
     mels = torch.randn(9, 3, 1, 128, 204, generator=torch.Generator().manual_seed(13))
     yield "audio", HipTower("audio", ib.synthetic_state(spec, seed=32, init="rich"), depth=3), mels, 1, 2

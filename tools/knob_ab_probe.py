@@ -12,6 +12,7 @@ from probe_common import load_probe, setter
 L, lib = load_probe()
 knob, va, vb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 out_path = sys.argv[4] if len(sys.argv) > 4 else None
+only = sys.argv[5] if len(sys.argv) > 5 else None                 # e.g. vision:32,36,40 -- one tower, these batch sizes
 set_knob = setter(lib, knob)
 from hippomm_amd.encoder import HipTower, synthetic_state_dict   # noqa: E402
 
@@ -28,7 +29,11 @@ def wall_ms(fn, iters):
 
 
 rows = []
-for kind, batches in (("text", (1, 4, 9, 16, 32, 64, 96)), ("vision", (1, 2, 3, 8, 12, 13, 14, 15, 16, 20, 22, 24, 26, 28, 32, 48, 64, 256)), ("audio", (1, 2, 4, 6, 8, 12, 16, 32, 128))):
+plan = (("text", (1, 4, 9, 16, 32, 64, 96)), ("vision", (1, 2, 3, 8, 12, 13, 14, 15, 16, 20, 22, 24, 26, 28, 32, 48, 64, 256)),
+        ("audio", (1, 2, 4, 6, 8, 12, 16, 32, 128)))
+if only:
+    plan = ((only.split(":")[0], tuple(int(b) for b in only.split(":")[1].split(","))),)
+for kind, batches in plan:
     tower = HipTower(kind, synthetic_state_dict((kind,), seed=99))
     for B in batches:
         if kind == "text":
