@@ -26,7 +26,7 @@ namespace hmm {
 
 HMM_TUNABLE(int, g_enc_side_priority, 0) // probe build: HIP priority of the second chain's stream (0 normal, 1 low, -1 high), read at create
 HMM_TUNABLE(int, g_enc_split_min, 13)    // frames of a vision forward from which it runs as two chains on two streams (round 5, tools/mid_batch_probe.py, profiles/r5_mid_batch.log: 13 / 14 / 15 frames 7.39 / 7.92 / 8.02 -> 6.78 / 6.92 / 6.93 ms, 8 ... 12 frames faster as one chain, 16 ... 56 frames 0 ... -14 %)
-HMM_TUNABLE(int, g_enc_split_min_text, 64)  // the same for the text tower (a wash below 64 questions)
+HMM_TUNABLE(int, g_enc_split_min_text, 54)  // the same for the text tower: 54 questions = 4158 rows is where one chain's launches cross 16 row tiles of 256 (54 ... 62 questions 4.76 ... 5.28 -> 4.14 ... 4.50 ms as two chains; 24 ... 52 questions 8 ... 13 % slower as two; profiles/r5_split_min_text_ab.json)
 HMM_TUNABLE(int, g_enc_two_chain_small_tiles, 64)  // gemm_set_small_tiles of a two-chain forward
 HMM_TUNABLE(int, g_enc_split_min_audio, 12) // the audio tower's smaller kernels overlap from 4 segments on (-7 .. -11 %; tools/split_min_probe.py)
 HMM_TUNABLE(int, g_enc_split_num, 128)   // frames of 256 that go to the first of the two chains

@@ -120,7 +120,7 @@ class HipTower:
         _lib.check(self._lib.hmm_encoder_set_fused_attention(self._h, int(bool(on))), "hmm_encoder_set_fused_attention")
 
     def set_streams(self, n: int):
-        """2 (default): half-batches on two streams from 13 frames / 4 audio segments / 64 questions on; 1: a single chain."""
+        """2 (default): half-batches on two streams from 13 frames / 4 audio segments / 54 questions on; 1: a single chain."""
         _lib.check(self._lib.hmm_encoder_set_streams(self._h, int(n)), "hmm_encoder_set_streams")
 
     def _workspace(self, batch: int) -> torch.Tensor:
