@@ -43,3 +43,37 @@ def test_scans_are_repeatable_and_rank_like_fp64():
         want = torch.topk(d, 33)
         sep = (want.values[:-1] - want.values[1:])[:32] > 2e-6          # fp32 sums: order is only pinned where fp64 separates
         assert torch.equal(first[("one", qi)][0][sep], want.indices[:32][sep])
+
+
+def test_few_row_forwards_are_repeatable_beside_a_busy_stream():
+    """The few-row regime (split-K fc2 reduced inside the next LayerNorm, 128 x 64 / eight-wave ring tiles): one frame, one
+    question, one audio segment and a few more, repeated with a large GEMM running on a second stream -- every run the same bits."""
+    from hippomm_amd import _lib as L
+    from hippomm_amd.encoder import HipTower
+    from oracle import imagebind_oracle as ib
+    lib = L.load()
+    side = torch.cuda.Stream()
+    big_a = torch.randn(8192, 1280, device="cuda").to(torch.bfloat16)
+    big_w = torch.randn(5120, 1280, device="cuda").to(torch.bfloat16)
+    big_b = torch.zeros(5120, device="cuda")
+    big_c = torch.empty(8192, 5120, dtype=torch.bfloat16, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(2)
+    cases = (("vision", ib.VISION_HUGE, lambda b: torch.randn(b, 3, 224, 224, device="cuda", generator=g), (1, 2, 3)),
+             ("audio", ib.AUDIO_HUGE, lambda b: torch.randn(b, 3, 1, 128, 204, device="cuda", generator=g), (1, 2)),
+             ("text", ib.TEXT_HUGE, lambda b: torch.randint(1, 49000, (b, 77), device="cuda", generator=g), (1, 4, 9, 10)))
+    for name, full, make, batches in cases:
+        spec = ib.reduced(full, 4)
+        tower = HipTower(name, ib.synthetic_state(spec, seed=5, init="rich"), depth=4)
+        for b in batches:
+            x = make(b)
+            if name == "text":
+                x[:, 0], x[:, 30] = 49406, 49407
+            ref = tower(x).clone()
+            for i in range(25):
+                if i % 2 == 0:
+                    with torch.cuda.stream(side):
+                        L.check(lib.hmm_op_gemm_bf16(big_a.data_ptr(), big_w.data_ptr(), big_b.data_ptr(), big_c.data_ptr(), 8192, 5120, 1280, 1,
+                                                     side.cuda_stream), "load")
+                assert torch.equal(tower(x), ref), f"{name} batch {b}: forward {i} differs from the first one"
+        del tower
+    torch.cuda.synchronize()
