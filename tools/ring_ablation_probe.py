@@ -11,7 +11,7 @@ from probe_common import load_probe, event_ms
 
 L, lib = load_probe()
 st = L.stream_ptr()
-T128 = {"full": 14, "no_mfma": 101, "no_reads_no_mfma": 102, "no_dma": 103, "5_stages": 105, "3_stages": 106, "staggered": 16}
+T128 = {"full": 14, "no_mfma": 101, "no_reads_no_mfma": 102, "no_dma": 103, "5_stages": 105, "3_stages": 106}
 T64 = {"full": 7, "no_mfma": 111, "no_reads_no_mfma": 112, "no_dma": 113}
 rows = []
 for name, N, K, Ms in (("vision fc2", 1280, 5120, (257, 2570)), ("vision fc1", 5120, 1280, (257, 2570)), ("vision qkv", 3840, 1280, (257,))):
