@@ -12,14 +12,14 @@ lib.hmm_probe_grid_barrier.restype = C.c_int
 lib.hmm_probe_grid_barrier.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
 lib.hmm_probe_empty_launches.restype = C.c_int
 lib.hmm_probe_empty_launches.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
-ctr = torch.zeros(16, dtype=torch.int32, device="cuda")
+ctr = torch.zeros(512, dtype=torch.int32, device="cuda")
 buf = torch.zeros(256 * 65536, dtype=torch.float32, device="cuda")
 stamps = torch.zeros(512, dtype=torch.int64, device="cuda")
 res = []
-ROUNDS = 2000
-for threads in (256, 512):
+ROUNDS = 1000
+for threads in (256,):
     for blocks in (64, 128, 256):
-        for mode in (0, 1, 2):
+        for mode in (0, 3, 4, 5):
             for work in (0, 4096):
                 def run():
                     L.check(lib.hmm_probe_grid_barrier(ctr.data_ptr(), blocks, threads, ROUNDS, mode, buf.data_ptr(), work,
@@ -28,7 +28,8 @@ for threads in (256, 512):
                 s = stamps.cpu()[: 2 * blocks].view(-1, 2)
                 inside = float((s[:, 1].max() - s[:, 0].min()).item()) / 100.0 / ROUNDS        # s_memrealtime: 100 MHz
                 rec = {"threads": threads, "blocks": blocks, "mode": mode, "work_floats_per_wg": work,
-                       "us_per_round_events": round(ms * 1e3 / ROUNDS, 3), "us_per_round_in_kernel": round(inside, 3)}
+                       "us_per_round_events": round(ms * 1e3 / ROUNDS, 3), "us_per_round_in_kernel": round(inside, 3),
+                       "spin_limit_hit": int(ctr[15].item())}
                 res.append(rec)
                 print(rec, flush=True)
 for blocks, threads in ((1, 64), (256, 256), (1024, 256)):
