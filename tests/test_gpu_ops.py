@@ -73,6 +73,50 @@ def test_gemm_epilogues_bitwise_equal_across_tile_geometries():
             assert torch.equal(o, outs[0]), f"epilogue {epi}: tile geometry {v} differs from 128x128"
 
 
+def _dispatch_fuzz_shapes():
+    """Seeded shapes around every row / tile-count limit of the dispatcher (gemm_bf16.hip: sliver vs ring, 32 / 64 / 128-row ring
+    tiles and their deep-K forms, the 128 x 64 rule up to 320 rows, one 128 x 128 ring tile per CU, ping-pong with peeled tails)."""
+    rng = np.random.default_rng(20261003)
+    Ns, Ks = (128, 256, 768, 1024, 1280, 2304, 3072, 3840, 4096, 5120), (64, 128, 192, 256, 768, 1024, 1280, 3072, 4096, 5120)
+    edge_m = (1, 15, 16, 17, 31, 33, 63, 64, 65, 77, 127, 128, 129, 229, 255, 256, 257, 319, 320, 321, 514, 640, 687, 693, 771, 1028,
+              2056, 2570, 3084, 3341, 4112)
+    shapes = []
+    for i in range(56):
+        M = int(edge_m[i % len(edge_m)]) if i < 40 else int(np.exp(rng.uniform(0, np.log(5000))))
+        shapes.append((M, int(rng.choice(Ns)), int(rng.choice(Ks)), int(rng.integers(0, 4))))
+    return shapes
+
+
+@pytest.mark.parametrize("M,N,K,epi", _dispatch_fuzz_shapes())
+def test_gemm_dispatcher_fuzz_auto_choice_has_the_bits_of_the_reference_tile(M, N, K, epi):
+    """Whatever kernel the dispatcher picks for a shape (AUTO: incl. the sliver kernel; AUTO_TILED: what the towers use) -- the
+    output has the bits of the double-buffered 128 x 128 kernel and is close to fp32 torch; rows past M stay untouched."""
+    L, lib = _lib()
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K + epi)
+    a = _bf16(torch.randn(M, K, device="cuda", generator=g))
+    w = _bf16(torch.randn(N, K, device="cuda", generator=g) * 0.05)
+    bias = torch.randn(N, device="cuda", generator=g)
+    dtype = torch.float32 if epi in (EPI_BIAS_RESID_F32, EPI_F32) else torch.bfloat16
+    c0 = (torch.randn(M + 2, N, device="cuda", generator=g) * 2.0).to(dtype)
+    outs = {}
+    for tile in (0, -1, -2):
+        c = c0.clone()
+        L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K, epi, tile, L.stream_ptr()), "gemm")
+        outs[tile] = c
+    assert torch.equal(outs[-1], outs[0]), "AUTO differs from the reference tile"
+    assert torch.equal(outs[-2], outs[0]), "AUTO_TILED differs from the reference tile"
+    assert torch.equal(outs[0][M:], c0[M:]), "rows past M were written"
+    want = a.float() @ w.float().T + bias                         # EPI_F32 adds the bias too when it is non-null
+    if epi == EPI_BIAS_GELU_BF16:
+        want = F.gelu(want)
+    if epi == EPI_BIAS_RESID_F32:
+        want = want + c0[:M]
+    if dtype == torch.bfloat16:
+        _close_bf16(outs[0][:M], want, extra_atol=2e-3)
+    else:
+        assert torch.allclose(outs[0][:M], want, rtol=2e-4, atol=2e-3 * float(want.abs().max()) / 10 + 1e-3)
+
+
 @pytest.mark.parametrize("M,N,K", [(77, 3072, 1024), (77, 1024, 4096), (1, 1024, 1024), (128, 5120, 1280), (16, 1280, 5120),
                                    (100, 768, 3072), (257, 3840, 1280), (640, 3840, 1280)])
 def test_gemm_few_rows_sliver_kernel_bitwise_equal_to_the_tiled_kernels(M, N, K):
