@@ -34,9 +34,16 @@ def sampler():
 
 th = threading.Thread(target=sampler, daemon=True)
 th.start()
-tower = HipTower("vision", synthetic_state_dict(("vision",), seed=1234))
+torch.cuda.init()
+torch.zeros(1, device="cuda")
 rows = []
 cap = int(open(CAPF).read()) / 1e6 if os.path.exists(CAPF) else None
+time.sleep(3.0)                                                    # the idle board (context created, nothing running)
+v = [(w, f) for t, w, f in samples[len(samples) // 3:]]
+rows.append({"frames": 0, "what": "idle, HIP context created", "watts_mean": round(sum(w for w, _ in v) / len(v), 1),
+             "sclk_mhz_mean": round(sum(f for _, f in v) / len(v), 1), "power_cap_w": cap, "samples": len(v)})
+print(json.dumps(rows[-1]), flush=True)
+tower = HipTower("vision", synthetic_state_dict(("vision",), seed=1234))
 for B in (1, 4, 8, 16, 32, 64, 128, 256):
     x = torch.randn(B, 3, 224, 224, device="cuda")
     out = torch.empty(B, 1024, device="cuda")
