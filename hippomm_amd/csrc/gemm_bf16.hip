@@ -835,8 +835,25 @@ int gemm_set_small_tiles(int tiles) {
 HMM_TUNABLE(int, g_gemm_small_by_r128, 1) // probe build: 0 = the small-tile decision on the count of 256 x 256 tiles alone (round 4)
 HMM_TUNABLE(int, g_gemm_rect, 1)          // probe build: 0 = never the 128 x 64 ring tiles (A/B)
 HMM_TUNABLE(int, g_gemm_tail_64, 128)      // the peeled last row tile of a big launch uses 64x64 tiles up to this many of them
+HMM_TUNABLE(int, g_gemm_ring_peel_rows, 16) // a last row tile of at most this many rows is peeled off a ring launch that it pushes past one tile per CU; 0 = never
 static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                                  int epi, hipStream_t st, bool tail = false) {
+    if (g_gemm_small_stages != 2 && !tail && g_gemm_ring_peel_rows > 0) {
+        // A frame is 257 token rows = two 128-row tiles + ONE row: k frames end in a row tile of k rows.  When that sliver of a tile
+        // is what pushes the launch past one 128 x 128 ring tile per CU (three frames' fc1: 7 x 40 = 280 tiles for 6 x 40 + 3 rows;
+        // four frames' qkv: 9 x 30 = 270), peel it: the full row tiles in one round of the ring, the last rows through the
+        // one-wave sliver kernel.  Same MFMA sequence per output element: same bits.
+        const int tm = (M + 127) / 128, tail_rows = M - (tm - 1) * 128;
+        const long cols = N / 128;
+        if (tm > 1 && tail_rows <= g_gemm_ring_peel_rows && tm * cols > kNumCU && (tm - 1) * cols <= kNumCU) {
+            const int m_main = (tm - 1) * 128;
+            int rc = launch_gemm_small_epi(A, W, bias, C, m_main, N, K, epi, st, false);
+            if (rc != HMM_OK) return rc;
+            const bool c_bf16 = epi == HMM_EPI_BIAS_BF16 || epi == HMM_EPI_BIAS_GELU_BF16;
+            return launch_gemm_sliver_epi(A + (size_t)m_main * K, W, bias, static_cast<char*>(C) + (size_t)m_main * N * (c_bf16 ? 2 : 4),
+                                          tail_rows, N, K, epi, st);
+        }
+    }
     if (g_gemm_small_stages == 2 || (long)((M + 127) / 128) * (N / 128) > 256)
         return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
     if (!tail && epi <= HMM_EPI_F32 && ring32_fits(M, N)) {

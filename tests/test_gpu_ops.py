@@ -84,6 +84,8 @@ def _dispatch_fuzz_shapes():
     for i in range(56):
         M = int(edge_m[i % len(edge_m)]) if i < 40 else int(np.exp(rng.uniform(0, np.log(5000))))
         shapes.append((M, int(rng.choice(Ns)), int(rng.choice(Ks)), int(rng.integers(0, 4))))
+    # the ring tail peel: three frames' fc1 (7 x 40 ring tiles for 6 x 40 + 3 rows), four frames' qkv, and its limits (16 / 17 tail rows)
+    shapes += [(771, 5120, 1280, 1), (1028, 3840, 1280, 0), (771, 5120, 256, 2), (768 + 16, 5120, 128, 3), (768 + 17, 5120, 128, 0)]
     return shapes
 
 
