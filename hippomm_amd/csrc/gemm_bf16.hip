@@ -112,9 +112,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], const float*
 // once per KSUB x 64 columns of K -- for launches of few rows, where a workgroup is alone on its CU and every step is a chain
 // of latencies, not of MFMAs.  K / 64 must be a multiple of KSUB (the launcher checks).  Same MFMA order, same bits.
 // (A staggered loop for the eight-wave tiles -- waves 4-7 half a K-tile behind waves 0-3, the ping-pong kernel's schedule at ring
-// size -- was built in round 5: bit-equal, 0 ... +4 % slower; profiles/LABNOTES_r5.md 13.)
+// size -- was built in round 5: bit-equal, 0 ... +4 % slower on the 128-row tiles; -14 % on a 256 x 128 tile, which is 25-30 % faster
+// alone than anything else on 13-16 frames' fc2 / out-proj and buys nothing in the forwards; profiles/LABNOTES_r5.md 13, 18.)
 // ABL (probe build, timing only -- results are wrong): 1 = no MFMAs, 2 = no fragment reads and no MFMAs, 3 = no LDS-DMA.
-template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2, int KSUB = 1, int ABL = 0, int STG = 0>
+template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2, int KSUB = 1, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     void* __restrict__ Cout, int M, int N, int K, int tiles_n, int tiles_m, int col_major, int k_len) {
@@ -249,81 +250,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-    } else if constexpr (STG != 0) {
-        // Phases alternate READ / MFMA with a barrier after each; group 0 (waves 0-3) reads K-tile kt in phase 2 kt, group 1
-        // (waves 4-7, the SIMD partners) in phase 2 kt + 1.  RAW: every wave retires its own pieces of K-tile kt (counted
-        // vmcnt) before the barrier that ends phase 2 kt - 1, i.e. before anybody's reads of kt.  WAR: K-tile kt + STAGES - 1
-        // goes into the buffer kt - 1 lived in and is requested in the wave's READ(kt) phase, which starts after the barrier
-        // that followed the last lgkmcnt(0) of READ(kt - 1) (group 1's, phase 2 kt - 1).
-        static_assert(NW == 8 && KSUB == 1 && STAGES > 2, "staggered loop: eight waves, plain ring");
-        constexpr int PER_STAGE = A_PER_WAVE + W_PER_WAVE;
-        static_assert(STAGES <= 8 && PER_STAGE * (STAGES - 2) <= 63, "vmcnt is a 6-bit counter");
-        const int grp = wave >> 2;                                   // waves w and w + 4 share a SIMD
-        auto wait_tile = [&](int kt) {                               // this wave's pieces of K-tile kt have landed
-            const int younger = KT - 1 - kt < STAGES - 2 ? KT - 1 - kt : STAGES - 2;
-            switch (younger) {
-                case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                case 1:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory"); break;
-                case 2:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * 2) : "memory"); break;
-                case 3:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (STAGES > 4 ? 3 : 0)) : "memory"); break;
-                case 4:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (STAGES > 5 ? 4 : 0)) : "memory"); break;
-                case 5:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (STAGES > 6 ? 5 : 0)) : "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (STAGES > 7 ? 6 : 0)) : "memory"); break;
-            }
-        };
-#define HMM_STG_BAR()                          \
-    __builtin_amdgcn_sched_barrier(0);         \
-    __builtin_amdgcn_s_barrier();              \
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int st = 0; st < STAGES - 1; ++st)
-            if (st < KT) stage(st, st);
-        wait_tile(0);
-        HMM_STG_BAR()
-        if (grp) { HMM_STG_BAR() }                                   // group 1 starts one phase late
-        int buf = 0;
-        bf16x8 af[2][MI], wf[2][NI];
-        for (int kt = 0; kt < KT; ++kt) {
-            // READ phase
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                const uint32_t pa = lds0 + buf * STAGE + a_off0 + (kh ? c_k1 : c_k0);
-                const uint32_t pw = lds0 + buf * STAGE + w_off0 + (kh ? c_k1 : c_k0);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[kh][mi]) : "v"(pa), "n"(mi * 2048));
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[kh][ni]) : "v"(pw), "n"(ni * 2048));
-            }
-            const int nxt = kt + STAGES - 1;
-            if (nxt < KT) stage(nxt, buf == 0 ? STAGES - 1 : buf - 1);
-            if (grp && kt + 1 < KT) wait_tile(kt + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) asm volatile("" : "+v"(af[kh][mi]));
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(wf[kh][ni]));
-            }
-            HMM_STG_BAR()
-            // MFMA phase
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][ni], af[kh][mi], acc[mi][ni], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            if (!grp && kt + 1 < KT) wait_tile(kt + 1);
-            HMM_STG_BAR()
-            buf = buf + 1 == STAGES ? 0 : buf + 1;
-        }
-        if (!grp) { HMM_STG_BAR() }                                  // re-align the two groups
-#undef HMM_STG_BAR
     } else {
         // Ring of STAGES K-tiles.  Iteration kt: wait for this wave's own pieces of K-tile kt (the younger K-tiles stay in
         // flight), barrier (RAW: every wave's pieces of kt have landed; WAR: every wave has finished reading kt - 1), request
@@ -714,7 +640,7 @@ HMM_TUNABLE(int, g_gemm_col_major, 0)
 static thread_local int t_gemm_tail_launch = 0;       // the peeled tail of a big launch keeps the row-major list (set by gemm_bf16)
 static thread_local int t_gemm_splits = 1;            // > 1: the next launch_gemm is a split-K launch (set by gemm_bf16_splitk)
 
-template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2, int KSUB = 1, int ABL = 0, int STG = 0>
+template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2, int KSUB = 1, int ABL = 0>
 static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                        hipStream_t st) {
     constexpr int LDS = STAGES * KSUB * (BM + BN) * 128;
@@ -723,7 +649,7 @@ static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void
     HMM_REQUIRE(K % splits == 0 && ((K / splits) / 64) % KSUB == 0 && (K / splits) % 64 == 0, HMM_E_INVALID,
                 "gemm: K = %d / %d splits is not a multiple of %d", K, splits, 64 * KSUB);
     HMM_REQUIRE(splits == 1 || (EPI == HMM_EPI_F32 && bias == nullptr), HMM_E_INVALID, "gemm: split-K writes fp32 partials only");
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, STAGES, KSUB, ABL, STG>;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, STAGES, KSUB, ABL>;
     HMM_ENSURE_DYN_LDS(kern, LDS);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
     const int col_major = g_gemm_col_major > 0 && !t_gemm_tail_launch && 2 * tiles_m <= tiles_n;
@@ -862,10 +788,10 @@ static int launch_gemm_ringk_epi(const bf16_t* A, const bf16_t* W, const float* 
 // its K walk times the workgroups a CU has to run one after (or beside) the other.  One frame's qkv GEMM is 300 tiles of 64 x 64
 // on 256 CUs -- 44 CUs run two workgroups and the launch takes their time, 13.3 us; as 128 x 64 tiles it is 180 workgroups, one per
 // CU, and the tile's 16 MFMAs per wave and K-tile hide the ring's latencies better than the 8 of a 64 x 64 tile.
-template <int BM, int BN, int WM = 2, int WN = 2, int STAGES = 4, int STG = 0>
+template <int BM, int BN, int WM = 2, int WN = 2>
 static int launch_gemm_ring_rect_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                                      int epi, hipStream_t st) {
-#define HMM_CALL(E) launch_gemm<BM, BN, WM, WN, E, STAGES, 1, 0, STG>(A, W, bias, C, M, N, K, st)
+#define HMM_CALL(E) launch_gemm<BM, BN, WM, WN, E, 4>(A, W, bias, C, M, N, K, st)
     switch (epi) {
         case HMM_EPI_BIAS_BF16:      return HMM_CALL(HMM_EPI_BIAS_BF16);
         case HMM_EPI_BIAS_GELU_BF16: return HMM_CALL(HMM_EPI_BIAS_GELU_BF16);
@@ -907,8 +833,6 @@ int gemm_set_small_tiles(int tiles) {
     t_gemm_small_tiles = tiles;
     return prev;
 }
-HMM_TUNABLE(int, g_gemm_ring256_pp_tiles, 0)   // launches of fewer 256 x 256 tiles than this may use the staggered 256 x 128 ring (see gemm_bf16); 0 = never
-HMM_TUNABLE(int, g_gemm_ring256_min_r128, 256) // ... when they are more than this many 128 x 128 ring tiles
 HMM_TUNABLE(int, g_gemm_small_by_r128, 1) // probe build: 0 = the small-tile decision on the count of 256 x 256 tiles alone (round 4)
 HMM_TUNABLE(int, g_gemm_rect, 1)          // probe build: 0 = never the 128 x 64 ring tiles (A/B)
 HMM_TUNABLE(int, g_gemm_tail_64, 128)      // the peeled last row tile of a big launch uses 64x64 tiles up to this many of them
@@ -994,11 +918,6 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         // rows) the 256-row count jumps a whole tile row early -- 65 ping-pong tiles for what is 250 ring tiles (24 frames on two
         // chains 10.50 -> 9.94 ms, profiles/r5_small_by_r128_ab.json)
         const long r128 = (long)((M + 127) / 128) * (N / 128);
-        // Few ping-pong tiles, more than one 128 x 128 ring tile per CU, at most one 256 x 128 ring tile per CU (fc2 / out-proj of
-        // 13-16 frames per chain: 70-85 ping-pong tiles on 256 CUs): the 256-row ring tile with the staggered loop
-        if (g_gemm_ring256_pp_tiles > 0 && tiles < g_gemm_ring256_pp_tiles && r128 > g_gemm_ring256_min_r128 &&
-            (long)tiles_m * (N / 128) <= kNumCU)
-            return launch_gemm_ring_rect_epi<256, 128, 4, 2, 3, 1>(A, W, bias, C, M, N, K, epi, st);
         if (tiles < t_gemm_small_tiles || (g_gemm_small_by_r128 && r128 <= kNumCU))
             return sliver_ok && sliver_wins(M, N, K, epi) ? launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, st)
                                              : launch_gemm_small_epi(A, W, bias, C, M, N, K, epi, st);
@@ -1034,10 +953,6 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         case HMM_GEMM_TILE_64x128_RING:   return launch_gemm_ring_rect_epi<64, 128>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_128x128_RING8: return launch_gemm_ring_rect_epi<128, 128, 2, 4>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_128x64_RING8:  return launch_gemm_ring_rect_epi<128, 64, 4, 2>(A, W, bias, C, M, N, K, epi, st);
-        case HMM_GEMM_TILE_256x128_RING8: return launch_gemm_ring_rect_epi<256, 128, 4, 2, 3>(A, W, bias, C, M, N, K, epi, st);
-        case 17: return launch_gemm_ring_rect_epi<256, 128, 4, 2, 3, 1>(A, W, bias, C, M, N, K, epi, st);   // staggered
-        case 18: return launch_gemm_ring_rect_epi<256, 128, 2, 4, 3, 1>(A, W, bias, C, M, N, K, epi, st);   // staggered, waves 2 x 4 (128 x 32 each)
-        case 19: return launch_gemm_ring_rect_epi<256, 128, 2, 4, 3, 0>(A, W, bias, C, M, N, K, epi, st);
 #ifdef HMM_PROBE
         // timing-only ablations of the eight-wave 128 x 128 ring (bias -> bf16 epilogue), five ring stages, and of the 64 x 64 ring
         case 101: return launch_gemm<128, 128, 2, 4, HMM_EPI_BIAS_BF16, 4, 1, 1>(A, W, bias, C, M, N, K, st);
