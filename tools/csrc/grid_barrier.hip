@@ -113,6 +113,23 @@ extern "C" int hmm_probe_grid_barrier(unsigned* ctr_dev, int blocks, int threads
     return HMM_OK;
 }
 
+// `n` dependent launches alternating two dynamic-LDS sizes (bytes), kernels that do nothing but touch their LDS: does a kernel that
+// asks for more than 64 KiB of LDS cost more at the boundary?
+__global__ void empty_lds_kernel(float* p) {
+    extern __shared__ float sm[];
+    if (threadIdx.x == 0) sm[0] = 1.f;
+    __syncthreads();
+    if (p && threadIdx.x == 999) p[0] = sm[0];
+}
+extern "C" int hmm_probe_empty_launches_lds(int n, int blocks, int threads, int lds_a, int lds_b, hmm_stream_t stream) {
+    using namespace hmm;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(empty_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (int i = 0; i < n; ++i) empty_lds_kernel<<<blocks, threads, (i & 1) ? lds_b : lds_a, st>>>(nullptr);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+
 // `n` dependent launches of a kernel that does nothing, in one stream: the per-launch floor
 extern "C" int hmm_probe_empty_launches(int n, int blocks, int threads, hmm_stream_t stream) {
     using namespace hmm;
