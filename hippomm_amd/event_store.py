@@ -131,25 +131,112 @@ def _fresh_manifest(json_path: Path) -> Optional[dict]:
     return None
 
 
-def parse_event_features(json_path) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
-    """Slow path, the reference's own reading rules (:369-408): new format with ``feature_times``, and the old
-    format where a modality maps to ``{'features': ..., 'times': ...}``.  Features come back as fp32."""
-    data = json.loads(Path(json_path).read_text())
+NATIVE_MIN_VALUES = 1024        # 2-D arrays of at least this many numbers are parsed by the library, the rest by json
+
+
+class _NativeMatrix:
+    """Placeholder json.loads leaves where the library parsed a matrix."""
+    __slots__ = ("array",)
+
+    def __init__(self, array):
+        self.array = array
+
+
+def _load_json_native(raw: bytes):
+    """``json.loads(raw)`` with every large 2-D array of numbers parsed by the library (``hmm_json_find_matrices`` /
+    ``hmm_json_parse_matrix_f32``: fp32, the value ``np.array(list).astype(float32)`` has) and left in the result as a
+    ``_NativeMatrix``.  None when the library declines (a literal outside the double range) or a matrix sits where this module
+    does not expect one -- the caller then uses plain ``json.loads``."""
+    import ctypes as C
+    from . import _lib as L
+    lib = L.load()
+
+    class Span(C.Structure):
+        _fields_ = [("begin", C.c_size_t), ("end", C.c_size_t), ("rows", C.c_size_t), ("cols", C.c_size_t)]
+
+    n = C.c_int(0)
+    cap = 16
+    while True:
+        spans = (Span * cap)()
+        L.check(lib.hmm_json_find_matrices(raw, len(raw), NATIVE_MIN_VALUES, C.cast(spans, C.c_void_p), cap, C.byref(n)), "hmm_json_find_matrices")
+        if n.value <= cap:
+            break
+        cap = n.value
+    if n.value == 0:
+        return json.loads(raw)
+    salt = uuid.uuid4().hex
+    pieces, mats, pos = [], {}, 0
+    for i in range(n.value):
+        sp = spans[i]
+        a = np.empty((sp.rows, sp.cols), np.float32)
+        if lib.hmm_json_parse_matrix_f32(raw, sp.begin, sp.end, sp.rows, sp.cols, a.ctypes.data_as(C.c_void_p)) != 0:
+            return None
+        token = f"@@hmm_matrix_{i}_{salt}@@"
+        mats[token] = a
+        pieces += [raw[pos:sp.begin], b'"' + token.encode() + b'"']
+        pos = sp.end
+    pieces.append(raw[pos:])
+    reduced = b"".join(pieces)
+    if any(reduced.count(t.encode()) != 1 for t in mats):          # the token also occurs in the event's own strings
+        return None
+
+    def put_back(v):
+        if isinstance(v, str) and v in mats:
+            return _NativeMatrix(mats[v])
+        if isinstance(v, dict):
+            return {k: put_back(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [put_back(x) for x in v]
+        return v
+    return put_back(json.loads(reduced))
+
+
+def parse_event_features(json_path, native: bool = True) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
+    """An event file without sidecars, by the reference's own reading rules (:369-408): new format with ``feature_times``, and
+    the old format where a modality maps to ``{'features': ..., 'times': ...}``.  Features come back as fp32.  With ``native`` the
+    feature matrices -- 99.9 % of the text -- are converted by the library instead of ``json.load`` + ``np.array(list)`` (~10x
+    faster, same values: tests/test_cpu_event_store.py); ``native=False`` is the reference's path as it stands."""
+    raw = Path(json_path).read_bytes()
+    data = _load_json_native(raw) if native else None
+    if data is not None:
+        # matrices are expected as feature values only; anywhere else (times, metadata) keeps the reference's float64 lists
+        feats_in = data.get("features") if isinstance(data, dict) else None
+        allowed = set()
+        if isinstance(feats_in, dict):
+            for d in feats_in.values():
+                if isinstance(d, _NativeMatrix):
+                    allowed.add(id(d))
+                elif isinstance(d, dict) and isinstance(d.get("features"), _NativeMatrix):
+                    allowed.add(id(d["features"]))
+
+        def stray(v):
+            if isinstance(v, _NativeMatrix):
+                return id(v) not in allowed
+            if isinstance(v, dict):
+                return any(stray(x) for x in v.values())
+            if isinstance(v, list):
+                return any(stray(x) for x in v)
+            return False
+        if stray(data):
+            data = None
+    if data is None:
+        data = json.loads(raw)
+    unwrap = lambda v: v.array if isinstance(v, _NativeMatrix) else np.array(v)     # noqa: E731
     feats, times = {}, {}
     if "feature_times" in data:
         for modality, t in data["feature_times"].items():
             times[modality] = np.array(t)
         for modality, f in data["features"].items():
-            feats[modality] = np.array(f)
+            feats[modality] = unwrap(f)
     else:
         for modality, d in data["features"].items():
             if isinstance(d, dict):
                 if "features" in d:
-                    feats[modality] = np.array(d["features"])
+                    feats[modality] = unwrap(d["features"])
                 if "times" in d:
                     times[modality] = np.array(d["times"])
             else:
-                feats[modality] = np.array(d)
+                feats[modality] = unwrap(d)
     return {modality: _as_feature_matrix(a) for modality, a in feats.items()}, times
 
 
@@ -190,14 +277,23 @@ def iter_event_files(memory_store_dir) -> Iterable[Tuple[str, Path]]:
         yield event_id, p
 
 
-def build_event_store(memory_store_dir, modality: str = "vision", device=None):
+def build_event_store(memory_store_dir, modality: str = "vision", device=None, workers: Optional[int] = None):
     """All events' ``modality`` matrices of a memory_store, resident in HBM.  Returns (EventStore, event_ids);
     events that lack the modality or whose width is not 1024 get an empty segment (the reference skips them
-    with a warning, :3135-3137)."""
+    with a warning, :3135-3137).  Event files are read by ``workers`` threads (default: min(16, cores)): the sidecar reads and
+    the library's matrix parser run outside the GIL, so a cold store loads in parallel; the order of the events is the index's."""
+    from concurrent.futures import ThreadPoolExecutor
     from .vector_ops import EventStore
+    files = list(iter_event_files(memory_store_dir))
+    if workers is None:
+        workers = min(16, os.cpu_count() or 1)
+    if workers > 1 and len(files) > 1:
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            loaded = list(pool.map(lambda f: load_event_features(f[1]), files))
+    else:
+        loaded = [load_event_features(path) for _, path in files]
     ids, mats = [], []
-    for event_id, path in iter_event_files(memory_store_dir):
-        feats = load_event_features(path)
+    for (event_id, path), feats in zip(files, loaded):
         a = feats.get(modality)
         if a is not None and a.ndim == 1 and a.shape[0] == 1024:
             a = a.reshape(1, 1024)                   # top_k_cosine_similarity treats a 1-D feature as one row (vector_ops.py:173-174)

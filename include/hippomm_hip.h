@@ -330,6 +330,18 @@ int hmm_op_scan_topk_only(const float* store_dev, int64_t n_rows, const float* q
 int hmm_op_scan_sims(const float* store_dev, int64_t n_rows, const float* query_dev, float* sims_dev,
                      hmm_stream_t stream);
 
+/* ---- memory_store event files: host-side parsing of the feature matrices (no GPU call) ----
+ * Replaces, for the 2-D arrays of numbers only, the json.load + np.array(list) of load_theta_event
+ * (hippomm/core/hippocampal_memory.py:369-395): hmm_json_find_matrices reports every `[[numbers], ...]` with equally long rows and
+ * at least min_values numbers in text[0, len) outside string literals (byte span of the outer brackets + shape; at most `cap`
+ * entries written, *n_found counts all); hmm_json_parse_matrix_f32 converts one reported span into rows x cols fp32,
+ * out[r][c] = (float)(double)literal with correctly rounded, locale-independent decimal -> double conversion -- the value
+ * np.array(json.load(f)[...]).astype(float32) has.  NaN / Infinity / -Infinity (Python's json spelling) are numbers here.  A
+ * literal outside the double range fails with HMM_E_INVALID: the caller keeps json.load for that file. */
+typedef struct hmm_json_matrix { size_t begin, end, rows, cols; } hmm_json_matrix;
+int hmm_json_find_matrices(const char* text, size_t len, size_t min_values, hmm_json_matrix* out, int cap, int* n_found);
+int hmm_json_parse_matrix_f32(const char* text, size_t begin, size_t end, size_t rows, size_t cols, float* out_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,3 +138,132 @@ def test_index_iteration(tmp_path):
     (base / "event_index.json").write_text(json.dumps(index, indent=2))
     got = list(es.iter_event_files(base))
     assert [g[0] for g in got] == list(index) and all(g[1].exists() for g in got)
+
+
+# ---- the library's matrix parser (hmm_json_find_matrices / hmm_json_parse_matrix_f32) against json.load + np.array ----
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _same(native, plain):
+    nf, nt = native
+    pf, pt = plain
+    assert nf.keys() == pf.keys() and nt.keys() == pt.keys()
+    for k in pf:
+        assert nf[k].dtype == np.float32 and nf[k].shape == pf[k].shape and np.array_equal(_bits(nf[k]), _bits(pf[k])), k
+    for k in pt:
+        assert nt[k].dtype == pt[k].dtype and np.array_equal(nt[k], pt[k]), k
+
+
+def test_native_matrix_parser_equals_json_load_on_the_golden_event_and_on_odd_values(tmp_path):
+    """Same fp32 bits and same times as the reference's reading rule, on the golden file and on an event holding NaN / inf / -0.0 /
+    subnormal / large / integer-valued entries and a matrix small enough to stay on json's path."""
+    _same(es.parse_event_features(GOLD, native=True), es.parse_event_features(GOLD, native=False))
+    rng = np.random.default_rng(11)
+    v = rng.standard_normal((48, 1024)).astype(np.float32)
+    v[0, :8] = [np.nan, np.inf, -np.inf, -0.0, 1e-42, -3.4e38, 16777217.0, 1e-7]
+    case = dict(recipes.event_case(), features={"vision": v, "vision_times": np.arange(48) * 0.5,
+                                                "audio": (rng.standard_normal((3, 1024)) * 20).astype(np.float32), "audio_times": [0.0, 10.0, 20.0],
+                                                "tiny": [[0.25, 0.5], [1.0, 2.0]], "tiny_times": [0.0, 1.0]})
+    p = es.save_event(case, tmp_path / "odd.json", write_sidecars=False)
+    native = es.parse_event_features(p, native=True)
+    _same(native, es.parse_event_features(p, native=False))
+    assert np.array_equal(_bits(native[0]["vision"]), _bits(v))
+
+
+def test_native_matrix_parser_old_format_strings_with_brackets_and_ragged_rows(tmp_path):
+    rng = np.random.default_rng(12)
+    v = rng.standard_normal((4, 1024)).astype(np.float32)
+    ragged = [[1.0] * 600, [2.0] * 599]                                # not a matrix: stays a list, np.array() of it is the reference's business
+    old = {"features": {"vision": {"features": v.tolist(), "times": [0.0, 1.0, 2.0, 3.0]}, "depth": v[:2].tolist()},
+           "summary": 'a string with [[1.0, 2.0], [3.0, 4.0]] and a quote \\" inside ' + "[[" + "1.5, " * 2000 + "1.5]]",
+           "frames": ["[[0.0]]"], "start_time": 0.0}
+    p = tmp_path / "old.json"
+    p.write_text(json.dumps(old, indent=2))
+    _same(es.parse_event_features(p, native=True), es.parse_event_features(p, native=False))
+    compact = tmp_path / "compact.json"                                # no whitespace at all, exponents, capital E
+    compact.write_text(json.dumps(old, separators=(",", ":")).replace("e-", "E-"))
+    _same(es.parse_event_features(compact, native=True), es.parse_event_features(compact, native=False))
+    bad = {"features": {"vision": v.tolist()}, "feature_times": {"vision_times": [0.0, 1.0, 2.0, 3.0]}, "extra": [[0.5] * 40] * 40}
+    p2 = tmp_path / "stray.json"                                       # a big matrix OUTSIDE features: the whole file takes json's path
+    p2.write_text(json.dumps(bad))
+    _same(es.parse_event_features(p2, native=True), es.parse_event_features(p2, native=False))
+
+
+def test_native_number_conversion_is_float32_of_float64_of_the_text():
+    """(float)(double)literal, bit for bit, on fp32 bit patterns, arbitrary doubles, and the decimals that sit on or next to a
+    rounding boundary between two floats (where the library's short cut must hand over to the exact conversion)."""
+    import ctypes as C
+    from hippomm_amd import _lib as L
+    lib = L.load()
+
+    class Span(C.Structure):
+        _fields_ = [("begin", C.c_size_t), ("end", C.c_size_t), ("rows", C.c_size_t), ("cols", C.c_size_t)]
+
+    def native(texts, cols=64):
+        rows = len(texts) // cols
+        raw = ("[" + ",".join("[" + ",".join(texts[r * cols:(r + 1) * cols]) + "]" for r in range(rows)) + "]").encode()
+        n, spans = C.c_int(0), (Span * 2)()
+        L.check(lib.hmm_json_find_matrices(raw, len(raw), 1, C.cast(spans, C.c_void_p), 2, C.byref(n)), "find")
+        assert n.value == 1 and (spans[0].rows, spans[0].cols, spans[0].begin, spans[0].end) == (rows, cols, 0, len(raw))
+        a = np.empty((rows, cols), np.float32)
+        L.check(lib.hmm_json_parse_matrix_f32(raw, 0, len(raw), rows, cols, a.ctypes.data_as(C.c_void_p)), "parse")
+        return a, np.array(json.loads(raw), dtype=np.float64).astype(np.float32)
+
+    rng = np.random.default_rng(13)
+    lit = lambda xs, fmt=repr: [fmt(float(x)).replace("inf", "Infinity").replace("nan", "NaN") for x in xs]   # noqa: E731
+    with np.errstate(all="ignore"):
+        f32 = rng.integers(0, 2 ** 32, 64 * 600, dtype=np.uint64).astype(np.uint32).view(np.float32)
+        f32 = f32[np.isfinite(f32)][:64 * 500]
+        d64 = rng.integers(0, 2 ** 64, 64 * 600, dtype=np.uint64).view(np.float64)
+        d64 = d64[np.isfinite(d64) & (np.abs(d64) < 1e300) & (np.abs(d64) > 1e-300)][:64 * 500]
+        f = np.abs(rng.standard_normal(64 * 100).astype(np.float32)) * np.float32(10.0) ** rng.integers(-30, 30, 64 * 100).astype(np.float32)
+        f = f[np.isfinite(f) & (f > 0)][:64 * 90]
+        mid = (f.astype(np.float64) + np.nextafter(f, np.float32(np.inf)).astype(np.float64)) / 2
+        special = [0.0, -0.0, 1.0, 5e-324, 1e-46, 1.4e-45, 7e-46, 3.4028234663852886e38, 3.4028235677973366e38, 3.5e38, 1e39, float("inf"),
+                   float("-inf"), float("nan"), 1e22, 1e23, 123456789012345678.0, 0.1, 1 / 3, 1e-5, 16777217.0, 9007199254740993.0] * 64
+        for tag, texts in (("fp32 bit patterns", lit(f32.astype(np.float64))), ("double bit patterns", lit(d64)),
+                           ("midpoints", lit(mid)), ("midpoints + 1 ulp", lit(np.nextafter(mid, np.inf))),
+                           ("midpoints - 1 ulp", lit(-np.nextafter(mid, -np.inf))), ("midpoints, 25 digits", lit(mid, lambda x: "%.24e" % x)),
+                           ("specials", lit(special[:64 * 22]))):
+            got, want = native(texts)
+            assert np.array_equal(_bits(got), _bits(want)), tag
+    got, want = native(["-0", "0", "7", "-12345678901"] * 16)
+    assert np.array_equal(_bits(got), _bits(want))                     # "-0" is an int for json: +0.0
+
+
+def test_native_parser_rejects_what_it_was_not_given():
+    import ctypes as C
+    from hippomm_amd import _lib as L
+    lib = L.load()
+    raw = b'{"a": [[1.0, 2.0], [3.0, 4.0]], "b": "x"}'
+    out = np.empty((2, 2), np.float32)
+    ptr = out.ctypes.data_as(C.c_void_p)
+    assert lib.hmm_json_parse_matrix_f32(raw, 6, 30, 2, 2, ptr) == 0 and out.tolist() == [[1.0, 2.0], [3.0, 4.0]]
+    assert lib.hmm_json_parse_matrix_f32(raw, 6, 30, 2, 3, ptr) != 0                  # wrong shape
+    assert lib.hmm_json_parse_matrix_f32(raw, 0, 30, 2, 2, ptr) != 0                  # span starts at '{'
+    assert lib.hmm_json_parse_matrix_f32(raw, 6, 6, 2, 2, ptr) != 0                   # empty span
+    assert b"json_parse_matrix" in lib.hmm_last_error()
+    huge = b"[[1e999, 1.0]]"                                                            # outside the double range: declined, not guessed
+    assert lib.hmm_json_parse_matrix_f32(huge, 0, len(huge), 1, 2, ptr) != 0
+    n = C.c_int(-1)
+    assert lib.hmm_json_find_matrices(b'"[[1.0, 2.0]]" [[1.0], [2.0, 3.0]] [[]] [1.0]', 44, 1, None, 0, C.byref(n)) == 0 and n.value == 0
+
+
+def test_build_event_store_reads_events_in_parallel_in_index_order(tmp_path, monkeypatch):
+    """Threads must not reorder events: the loaded matrices line up with the index whatever finishes first."""
+    rng = np.random.default_rng(14)
+    index, want = {}, []
+    for i in range(12):
+        v = rng.standard_normal((3 + i, 1024)).astype(np.float32)
+        ev = dict(recipes.event_case(), features={"vision": v, "vision_times": np.arange(3 + i) * 1.0})
+        p = es.save_event(ev, tmp_path / "events" / "vid" / f"e{i}.json", write_sidecars=bool(i % 2))
+        index[f"e{i}"] = {"file_path": str(p), "video_id": "vid"}
+        want.append(v)
+    (tmp_path / "event_index.json").write_text(json.dumps(index))
+    got = []
+    import hippomm_amd.vector_ops as vo
+    monkeypatch.setattr(vo, "EventStore", lambda mats, device: got.extend(mats) or "store")
+    store, ids = es.build_event_store(tmp_path, "vision", workers=4)
+    assert store == "store" and ids == [f"e{i}" for i in range(12)]
+    assert all(np.array_equal(_bits(a), _bits(b)) for a, b in zip(got, want))
