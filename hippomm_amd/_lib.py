@@ -70,6 +70,8 @@ _SIGNATURES = {
     "hmm_op_scan_sims": (C.c_int, [c_ptr, C.c_int64, c_ptr, c_ptr, c_ptr]),
     "hmm_json_find_matrices": (C.c_int, [C.c_char_p, C.c_size_t, C.c_size_t, c_ptr, C.c_int, C.POINTER(C.c_int)]),
     "hmm_json_parse_matrix_f32": (C.c_int, [C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, c_ptr]),
+    "hmm_json_matrix_text_bound": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_int]),
+    "hmm_json_write_matrix_f64": (C.c_int, [c_ptr, C.c_size_t, C.c_size_t, C.c_int, c_ptr, C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 
 

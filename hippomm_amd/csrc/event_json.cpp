@@ -282,3 +282,98 @@ extern "C" int hmm_json_parse_matrix_f32(const char* text, size_t begin, size_t 
     HMM_REQUIRE(k == total && depth == 0, HMM_E_INVALID, "json_parse_matrix: %zu numbers in the span, expected %zu x %zu", k, rows, cols);
     return HMM_OK;
 }
+
+// ---- writer: the text json.dumps(rows, indent=2) gives a list of equally long lists of floats, nested `close_indent` deep ----
+namespace {
+
+// float.__repr__ (and therefore json.dumps) of a finite double: the shortest digit string that round-trips (std::to_chars gives the
+// same digits as Python's dtoa mode 0), in fixed notation when -4 < decimal-point position <= 16, else d[.ddd]e+XX; "NaN" /
+// "Infinity" / "-Infinity" as json.dumps spells them.  Returns the end of the text.
+inline char* py_float_repr(double x, char* out) {
+    if (x != x) { std::memcpy(out, "NaN", 3); return out + 3; }
+    if (x < 0 || (x == 0 && __builtin_signbit(x))) { *out++ = '-'; x = -x; }
+    if (x == __builtin_inf()) { std::memcpy(out, "Infinity", 8); return out + 8; }
+    if (x == 0) { std::memcpy(out, "0.0", 3); return out + 3; }
+    char sci[40];
+    const auto r = std::to_chars(sci, sci + sizeof(sci), x, std::chars_format::scientific);      // d[.ddd]e[+-]XX
+    char digits[24];
+    int n = 0;
+    const char* p = sci;
+    for (; p < r.ptr && *p != 'e'; ++p)
+        if (*p != '.') digits[n++] = *p;
+    ++p;                                                       // past 'e'
+    const bool eneg = *p == '-';
+    ++p;
+    int e10 = 0;
+    for (; p < r.ptr; ++p) e10 = e10 * 10 + (*p - '0');
+    const int decpt = (eneg ? -e10 : e10) + 1;                 // value = 0.d1d2... x 10^decpt
+    if (decpt <= -4 || decpt > 16) {
+        *out++ = digits[0];
+        if (n > 1) { *out++ = '.'; std::memcpy(out, digits + 1, n - 1); out += n - 1; }
+        *out++ = 'e';
+        int e = decpt - 1;
+        *out++ = e < 0 ? '-' : '+';
+        if (e < 0) e = -e;
+        if (e >= 100) { *out++ = (char)('0' + e / 100); e %= 100; *out++ = (char)('0' + e / 10); *out++ = (char)('0' + e % 10); }
+        else { *out++ = (char)('0' + e / 10); *out++ = (char)('0' + e % 10); }
+        return out;
+    }
+    if (decpt <= 0) {
+        *out++ = '0'; *out++ = '.';
+        for (int i = 0; i < -decpt; ++i) *out++ = '0';
+        std::memcpy(out, digits, n);
+        return out + n;
+    }
+    if (decpt >= n) {
+        std::memcpy(out, digits, n); out += n;
+        for (int i = n; i < decpt; ++i) *out++ = '0';
+        *out++ = '.'; *out++ = '0';
+        return out;
+    }
+    std::memcpy(out, digits, decpt); out += decpt;
+    *out++ = '.';
+    std::memcpy(out, digits + decpt, n - decpt);
+    return out + (n - decpt);
+}
+
+inline char* put_spaces(char* out, int n) { std::memset(out, ' ', (size_t)n); return out + n; }
+
+}  // namespace
+
+// Upper bound of the bytes hmm_json_write_matrix_f64 writes.
+extern "C" size_t hmm_json_matrix_text_bound(size_t rows, size_t cols, int close_indent) {
+    const size_t ind = close_indent > 0 ? (size_t)close_indent : 0;
+    return 8 + ind + rows * (2 * (ind + 2) + 8 + cols * (26 + ind + 4 + 2));
+}
+
+// rows x cols doubles (row-major, host) as the text json.dumps(m.tolist(), indent=2) produces for that list when its closing bracket
+// sits at `close_indent` spaces (rows at +2, values at +4): byte for byte what save_theta_event writes
+// (hippomm/core/hippocampal_memory.py:331-335) for a feature matrix.  rows >= 1, cols >= 1.
+extern "C" int hmm_json_write_matrix_f64(const double* m, size_t rows, size_t cols, int close_indent, char* out_text, size_t cap,
+                                         size_t* written) {
+    HMM_REQUIRE(m && out_text && written && rows >= 1 && cols >= 1 && close_indent >= 0, HMM_E_INVALID, "json_write_matrix: bad arguments");
+    HMM_REQUIRE(cap >= hmm_json_matrix_text_bound(rows, cols, close_indent), HMM_E_INVALID, "json_write_matrix: buffer of %zu bytes, need %zu",
+                cap, hmm_json_matrix_text_bound(rows, cols, close_indent));
+    char* o = out_text;
+    *o++ = '[';
+    for (size_t r = 0; r < rows; ++r) {
+        if (r) *o++ = ',';
+        *o++ = '\n';
+        o = put_spaces(o, close_indent + 2);
+        *o++ = '[';
+        for (size_t c = 0; c < cols; ++c) {
+            if (c) *o++ = ',';
+            *o++ = '\n';
+            o = put_spaces(o, close_indent + 4);
+            o = py_float_repr(m[r * cols + c], o);
+        }
+        *o++ = '\n';
+        o = put_spaces(o, close_indent + 2);
+        *o++ = ']';
+    }
+    *o++ = '\n';
+    o = put_spaces(o, close_indent);
+    *o++ = ']';
+    *written = (size_t)(o - out_text);
+    return HMM_OK;
+}

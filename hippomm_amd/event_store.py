@@ -52,9 +52,8 @@ def event_json_text(event: Any, fast: bool = True) -> str:
     """Exactly the text ``save_theta_event`` writes (:334-335): ``json.dumps(event.to_dict(), indent=2)``.
 
     ``indent`` forces Python's pure-Python encoder (~1 us per float; 0.6 s for a 600-frame event).  With ``fast`` the
-    2-D feature matrices -- 99.9 % of the text -- are encoded row by row with the C encoder and re-indented by string
-    replacement, which yields the same bytes (same ``float.__repr__`` digits, same separators and indentation) 2-3x
-    faster; everything else, and any matrix that is not a non-empty list of equally long rows of Python floats (EVERY row is
+    2-D feature matrices -- 99.9 % of the text -- are written by the library (``_matrix_text``: the same bytes -- same
+    ``float.__repr__`` digits and notation, same separators and indentation); everything else, and any matrix that is not a non-empty list of equally long rows of Python floats (EVERY row is
     checked), goes through ``json.dumps(indent=2)`` itself.  The hole a matrix leaves in the outer text is a fresh random
     token; if the token turns up anywhere else in the text the whole event goes through ``json.dumps(indent=2)``."""
     d = event.to_dict() if hasattr(event, "to_dict") else event_to_dict(event)
@@ -63,7 +62,7 @@ def event_json_text(event: Any, fast: bool = True) -> str:
     feats, holes, salt = dict(d["features"]), {}, uuid.uuid4().hex
     for i, (modality, rows) in enumerate(list(feats.items())):
         if (isinstance(rows, list) and rows and isinstance(rows[0], list) and rows[0]
-                and all(type(r) is list and len(r) == len(rows[0]) and all(type(v) is float for v in r) for r in rows)):
+                and all(type(r) is list and len(r) == len(rows[0]) and set(map(type, r)) == {float} for r in rows)):   # every value a float
             token = f"@@hmm_matrix_{i}_{salt}@@"
             holes[f'"{token}"'] = rows
             feats[modality] = token
@@ -72,9 +71,27 @@ def event_json_text(event: Any, fast: bool = True) -> str:
         return json.dumps(d, indent=2)
     for quoted, rows in holes.items():
         # features -> modality -> row -> value: rows sit at indent 6, values at indent 8, the closing bracket at indent 4
-        body = ",\n".join("      [\n        " + json.dumps(r)[1:-1].replace(", ", ",\n        ") + "\n      ]" for r in rows)
-        text = text.replace(quoted, "[\n" + body + "\n    ]", 1)
+        text = text.replace(quoted, _matrix_text(rows), 1)
     return text
+
+
+def _matrix_text(rows, native: bool = True) -> str:
+    """``json.dumps(rows, indent=2)`` of a non-empty list of equally long lists of floats whose closing bracket sits at indent 4.
+    ``native``: written by the library (``hmm_json_write_matrix_f64``: float.__repr__ digits and notation, byte for byte --
+    tests/test_cpu_event_store.py); otherwise row by row with the C encoder of ``json`` and re-indented."""
+    if native:
+        import ctypes as C
+        from . import _lib as L
+        lib = L.load()
+        m = np.array(rows, dtype=np.float64)
+        cap = lib.hmm_json_matrix_text_bound(m.shape[0], m.shape[1], 4)
+        buf = C.create_string_buffer(cap)
+        n = C.c_size_t(0)
+        L.check(lib.hmm_json_write_matrix_f64(m.ctypes.data_as(C.c_void_p), m.shape[0], m.shape[1], 4, C.cast(buf, C.c_void_p), cap, C.byref(n)),
+                "hmm_json_write_matrix_f64")
+        return buf.raw[:n.value].decode("ascii")
+    body = ",\n".join("      [\n        " + json.dumps(r)[1:-1].replace(", ", ",\n        ") + "\n      ]" for r in rows)
+    return "[\n" + body + "\n    ]"
 
 
 def _sidecar_paths(json_path: Path, modality: str) -> Tuple[Path, Path]:

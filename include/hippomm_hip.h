@@ -341,6 +341,12 @@ int hmm_op_scan_sims(const float* store_dev, int64_t n_rows, const float* query_
 typedef struct hmm_json_matrix { size_t begin, end, rows, cols; } hmm_json_matrix;
 int hmm_json_find_matrices(const char* text, size_t len, size_t min_values, hmm_json_matrix* out, int cap, int* n_found);
 int hmm_json_parse_matrix_f32(const char* text, size_t begin, size_t end, size_t rows, size_t cols, float* out_host);
+/* The writer's side (save_theta_event, hippocampal_memory.py:331-335: json.dump(event.to_dict(), f, indent=2)): rows x cols host
+ * doubles as the text json.dumps(m.tolist(), indent=2) has for that list when its closing bracket sits at close_indent spaces
+ * (rows at +2, values at +4) -- float.__repr__ digits and notation, NaN / Infinity / -Infinity as json spells them; byte for byte.
+ * out_text needs hmm_json_matrix_text_bound(rows, cols, close_indent) bytes; *written = the length (no terminator). */
+size_t hmm_json_matrix_text_bound(size_t rows, size_t cols, int close_indent);
+int hmm_json_write_matrix_f64(const double* m_host, size_t rows, size_t cols, int close_indent, char* out_text, size_t cap, size_t* written);
 
 #ifdef __cplusplus
 }

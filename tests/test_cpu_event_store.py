@@ -267,3 +267,24 @@ def test_build_event_store_reads_events_in_parallel_in_index_order(tmp_path, mon
     store, ids = es.build_event_store(tmp_path, "vision", workers=4)
     assert store == "store" and ids == [f"e{i}" for i in range(12)]
     assert all(np.array_equal(_bits(a), _bits(b)) for a, b in zip(got, want))
+
+
+def test_native_matrix_writer_is_json_dumps_indent_2_byte_for_byte():
+    """hmm_json_write_matrix_f64 against json.dumps on fp32-origin values, arbitrary doubles, every power of ten, integers-valued
+    floats and the notation switch points of float.__repr__ (1e16 / 1e15, 1e-4 / 1e-5), NaN / Infinity / -0.0."""
+    rng = np.random.default_rng(15)
+
+    def want(m):
+        t = json.dumps({"a": {"b": m.tolist()}}, indent=2)           # closing bracket at indent 4, as features -> modality -> matrix
+        return t[t.index("["):t.rindex("]") + 1]
+
+    with np.errstate(all="ignore"):
+        cases = [rng.integers(0, 2 ** 32, 64 * 800, dtype=np.uint64).astype(np.uint32).view(np.float32).astype(np.float64),
+                 rng.integers(0, 2 ** 64, 64 * 800, dtype=np.uint64).view(np.float64), rng.standard_normal(64 * 400),
+                 np.array([10.0 ** e for e in range(-323, 309)])[:64 * 9], rng.integers(-10 ** 17, 10 ** 17, 64 * 100).astype(np.float64),
+                 np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 1e16, 9999999999999998.0, 1e15,
+                           0.0001, 0.00001, 123456789012345680.0, 1234567.0, 0.1, 100.0, 1e22, 1e23, 1e-7, 1 / 3, 1e21, 9.999e-5, 1.5, -2.5e-10, 16777217.0] * 64)[:64 * 26]]
+    for v in cases:
+        m = v[: (len(v) // 64) * 64].reshape(-1, 64)
+        assert es._matrix_text(m.tolist(), native=True) == want(m) == es._matrix_text(m.tolist(), native=False)
+    assert es._matrix_text([[0.5]], native=True) == want(np.array([[0.5]]))
