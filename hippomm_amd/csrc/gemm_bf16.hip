@@ -835,6 +835,8 @@ int gemm_set_small_tiles(int tiles) {
 }
 HMM_TUNABLE(int, g_gemm_small_by_r128, 1) // probe build: 0 = the small-tile decision on the count of 256 x 256 tiles alone (round 4)
 HMM_TUNABLE(int, g_gemm_rect, 1)          // probe build: 0 = never the 128 x 64 ring tiles (A/B)
+HMM_TUNABLE(int, g_gemm_pp_bias_tiles, 88)    // see launch_gemm_small_epi; 0 = never
+HMM_TUNABLE(int, g_gemm_rect64_min_t64, 450) // launches of at least this many 64 x 64 tiles (and at most 256 tiles of 64 x 128) use 64 x 128 ring tiles; 0 = never
 HMM_TUNABLE(int, g_gemm_rect_rows_longk, 1536) // the 128 x 64 rule's row limit for K >= 5120 (fc2 of three to five frames: 20 column tiles x 7-11 row tiles); 0 = 320 as for every other GEMM
 HMM_TUNABLE(int, g_gemm_tail_64, 128)      // the peeled last row tile of a big launch uses 64x64 tiles up to this many of them
 HMM_TUNABLE(int, g_gemm_ring_peel_rows, 16) // a last row tile of at most this many rows is peeled off a ring launch that it pushes past one tile per CU; 0 = never
@@ -856,8 +858,14 @@ static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* 
                                           tail_rows, N, K, epi, st);
         }
     }
-    if (g_gemm_small_stages == 2 || (long)((M + 127) / 128) * (N / 128) > 256)
+    if (g_gemm_small_stages == 2 || (long)((M + 127) / 128) * (N / 128) > 256) {
+        // past one ring tile per CU.  With the plain bias -> bf16 epilogue (qkv) the ping-pong tile already wins from ~88 tiles on
+        // (five to seven frames' qkv: 90-120 tiles, 25.4-25.7 us against 27.2-28.3); with the GELU epilogue (fc1) it does not
+        if (g_gemm_pp_bias_tiles > 0 && !tail && epi == HMM_EPI_BIAS_BF16 && N % 256 == 0 && K % 128 == 0 &&
+            (long)((M + 255) / 256) * (N / 256) >= g_gemm_pp_bias_tiles && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31))
+            return launch_gemm_pp<HMM_EPI_BIAS_BF16>(A, W, bias, C, M, N, K, st);
         return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
+    }
     if (!tail && epi <= HMM_EPI_F32 && ring32_fits(M, N)) {
         // deep-K rings while the launch leaves most CUs a workgroup of their own (tools/deepk_probe.py, cold weights): one
         // question's fc2 (96 tiles, K = 4096) 16.4 -> 10.5 us with four K-tiles per stage, its out-proj 6.3 -> 5.3 with two
@@ -880,6 +888,12 @@ static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* 
             (long)((M + 127) / 128) * (N / 64) <= kNumCU)
             return g_gemm_ring8 ? launch_gemm_ring_rect_epi<128, 64, 4, 2>(A, W, bias, C, M, N, K, epi, st)
                                 : launch_gemm_ring_rect_epi<128, 64>(A, W, bias, C, M, N, K, epi, st);
+        // well past one 64 x 64 tile per CU (two workgroups side by side on most CUs) but at most one 64 x 128 tile per CU: the
+        // 64-row x 128-column ring tile (four waves of 32 x 64) -- six frames' out-proj / fc2 (forward -6.3 %), 24-26 questions' (-2.4 /
+        // -4 %); from 450 tiles on: at 432 (22 questions) it loses 3 % (profiles/r5_dispatch_audit_ab.json, LABNOTES_r5 17)
+        if (g_gemm_rect64_min_t64 > 0 && !tail && (long)((M + 63) / 64) * (N / 64) >= g_gemm_rect64_min_t64 &&
+            (long)((M + 63) / 64) * (N / 128) <= kNumCU)
+            return launch_gemm_ring_rect_epi<64, 128>(A, W, bias, C, M, N, K, epi, st);
         // at most one 64x64 tile per CU: the deep-K ring (96 KiB, one workgroup per CU anyway) -- one frame's fc2 24.5 -> 21.9 us,
         // its out-proj 8.6 -> 8.0 (cold weights, tools/deepk_probe.py); with more tiles than CUs two plain-ring workgroups per CU win
         if (g_gemm_deepk && !tail && epi <= HMM_EPI_F32 && (K >> 6) % 2 == 0 && K >= 1024 && (long)((M + 63) / 64) * (N / 64) <= kNumCU)

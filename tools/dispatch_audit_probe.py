@@ -1,0 +1,57 @@
+"""Audit of the few-row GEMM dispatcher: for every GEMM of a vision block at 2 ... 12 frames' rows (and audio at 2 ... 8 segments, text at
+10 ... 40 questions) the dispatcher's choice against every named tile geometry, alone with COLD weights; prints the shapes where some
+geometry beats the choice by more than 5 %.  Candidates only: a rule is kept after an A/B in the forwards (tools/knob_ab_probe.py).
+usage: dispatch_audit_probe.py [out.json] [vision|audio|text]"""
+import json
+import sys
+
+import torch
+
+from probe_common import load_probe, event_ms
+
+L, lib = load_probe()
+EPI = {"bias": 0, "gelu": 1, "resid": 2}
+TILES = {"auto": -1, "db128": 0, "pp": 3, "ring128": 6, "ring64": 7, "ring64_k2": 11, "r128x64": 12, "r64x128": 13, "r128x128w8": 14, "r128x64w8": 15}
+st = L.stream_ptr()
+which = sys.argv[2] if len(sys.argv) > 2 else "vision"
+if which == "vision":
+    D, rows_per, counts = 1280, 257, range(2, 13)
+elif which == "audio":
+    D, rows_per, counts = 768, 687, range(2, 9)
+else:
+    D, rows_per, counts = 1024, 77, (10, 12, 14, 16, 20, 24, 28, 32, 40, 48)
+SHAPES = [("qkv", 3 * D, D, "bias"), ("fc1", 4 * D, D, "gelu"), ("out", D, D, "resid"), ("fc2", D, 4 * D, "resid")]
+rows = []
+for name, N, K, epi in SHAPES:
+    copies = max(4, int(400e6 // (N * K * 2)) + 1)
+    g = torch.Generator(device="cuda").manual_seed(N + K)
+    ws = [(torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16) for _ in range(copies)]
+    bias = torch.randn(N, device="cuda", generator=g)
+    for k in counts:
+        M = k * rows_per
+        a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+        c = torch.randn(M, N, device="cuda", generator=g) if epi == "resid" else torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        rec = {"tower": which, "gemm": name, "samples": k, "M": M, "N": N, "K": K}
+        state = {"i": 0}
+        for rep in range(2):                                   # the second pass runs at steady clocks and is the one kept
+            for tag, tile in TILES.items():
+                if tag == "pp" and (N % 256 or K % 128):
+                    continue
+                if tag in ("ring64", "ring64_k2") and ((M + 63) // 64) * (N // 64) > 1100:
+                    continue
+                if tag == "ring64_k2" and (K // 64) % 2:
+                    continue
+
+                def call():
+                    w = ws[state["i"] % copies]
+                    state["i"] += 1
+                    L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K, EPI[epi], tile, st), "gemm")
+                rec["us_" + tag] = round(event_ms(call, 2 * copies, warmup=copies) * 1e3, 2)
+        best = min((v, t) for t, v in rec.items() if t.startswith("us_") and t != "us_auto")
+        rec["best"], rec["auto_over_best"] = best[1][3:], round(rec["us_auto"] / best[0], 3)
+        rows.append(rec)
+        flag = "  <-- " if rec["auto_over_best"] > 1.05 else ""
+        print(json.dumps(rec) + flag, flush=True)
+        if len(sys.argv) > 1:
+            json.dump(rows, open(sys.argv[1], "w"), indent=1)
+    del ws
