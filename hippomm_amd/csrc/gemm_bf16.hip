@@ -835,7 +835,7 @@ int gemm_set_small_tiles(int tiles) {
 }
 HMM_TUNABLE(int, g_gemm_small_by_r128, 1) // probe build: 0 = the small-tile decision on the count of 256 x 256 tiles alone (round 4)
 HMM_TUNABLE(int, g_gemm_rect, 1)          // probe build: 0 = never the 128 x 64 ring tiles (A/B)
-HMM_TUNABLE(int, g_gemm_pp_bias_tiles, 88)    // see launch_gemm_small_epi; 0 = never
+HMM_TUNABLE(int, g_gemm_pp_bias_tiles, 80)    // see launch_gemm_small_epi; 0 = never
 HMM_TUNABLE(int, g_gemm_rect64_min_t64, 450) // launches of at least this many 64 x 64 tiles (and at most 256 tiles of 64 x 128) use 64 x 128 ring tiles; 0 = never
 HMM_TUNABLE(int, g_gemm_rect_rows_longk, 1536) // the 128 x 64 rule's row limit for K >= 5120 (fc2 of three to five frames: 20 column tiles x 7-11 row tiles); 0 = 320 as for every other GEMM
 HMM_TUNABLE(int, g_gemm_tail_64, 128)      // the peeled last row tile of a big launch uses 64x64 tiles up to this many of them
@@ -859,7 +859,7 @@ static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* 
         }
     }
     if (g_gemm_small_stages == 2 || (long)((M + 127) / 128) * (N / 128) > 256) {
-        // past one ring tile per CU.  With the plain bias -> bf16 epilogue (qkv) the ping-pong tile already wins from ~88 tiles on
+        // past one ring tile per CU.  With the plain bias -> bf16 epilogue (qkv) the ping-pong tile already wins from ~80 tiles on
         // (five to seven frames' qkv: 90-120 tiles, 25.4-25.7 us against 27.2-28.3); with the GELU epilogue (fc1) it does not
         if (g_gemm_pp_bias_tiles > 0 && !tail && epi == HMM_EPI_BIAS_BF16 && N % 256 == 0 && K % 128 == 0 &&
             (long)((M + 255) / 256) * (N / 256) >= g_gemm_pp_bias_tiles && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31))
