@@ -837,6 +837,7 @@ HMM_TUNABLE(int, g_gemm_small_by_r128, 1) // probe build: 0 = the small-tile dec
 HMM_TUNABLE(int, g_gemm_rect, 1)          // probe build: 0 = never the 128 x 64 ring tiles (A/B)
 HMM_TUNABLE(int, g_gemm_pp_bias_tiles, 80)    // see launch_gemm_small_epi; 0 = never
 HMM_TUNABLE(int, g_gemm_rect64_min_t64, 450) // launches of at least this many 64 x 64 tiles (and at most 256 tiles of 64 x 128) use 64 x 128 ring tiles; 0 = never
+HMM_TUNABLE(int, g_gemm_rect_rows, 700)        // row limit of the 128 x 64 rule (round 5: 320 with the four-wave tile; with eight waves it pays up to the few-row regime's 700 rows)
 HMM_TUNABLE(int, g_gemm_rect_rows_longk, 1536) // the 128 x 64 rule's row limit for K >= 5120 (fc2 of three to five frames: 20 column tiles x 7-11 row tiles); 0 = 320 as for every other GEMM
 HMM_TUNABLE(int, g_gemm_tail_64, 128)      // the peeled last row tile of a big launch uses 64x64 tiles up to this many of them
 HMM_TUNABLE(int, g_gemm_ring_peel_rows, 16) // a last row tile of at most this many rows is peeled off a ring launch that it pushes past one tile per CU; 0 = never
@@ -882,9 +883,11 @@ static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* 
         // 1.234 -> 1.224.  Beyond ~300 rows it loses in the forwards (one / two audio segments +1 / +10 %, three frames +1 %,
         // profiles/r5_rect_forward.json: the 128-row tile's K-step is 0.47 us against 0.29, which only pays while it halves the
         // workgroups per CU of a SHORT K walk), hence the row limit.  Over the LONGEST K walk (the vision tower's fc2, K = 5120) it pays
+        // (With the EIGHT-wave tile the general limit moved from 320 to 700 rows: 5 / 6 / 7 / 8 questions -6.3 / -8.4 / -2.1 / -1.4 %, one audio
+        // segment -1.7 %, profiles/r5_rect700_ab.json; 771 rows = three frames' out-proj is where it starts to lose.)  For K = 5120
         // up to 1536 rows: three / four / five frames -3.8 / -2.6 / -4.1 % (profiles/r5_rect_longk_ab.json); the text tower's fc2
         // (K = 4096, 16 column tiles) loses 2-3 % at 14-18 questions with the same rule, so the limit is by K.
-        if (g_gemm_rect && !tail && (M <= 320 || (M <= g_gemm_rect_rows_longk && K >= 5120)) && (long)((M + 63) / 64) * (N / 64) > kNumCU &&
+        if (g_gemm_rect && !tail && (M <= g_gemm_rect_rows || (M <= g_gemm_rect_rows_longk && K >= 5120)) && (long)((M + 63) / 64) * (N / 64) > kNumCU &&
             (long)((M + 127) / 128) * (N / 64) <= kNumCU)
             return g_gemm_ring8 ? launch_gemm_ring_rect_epi<128, 64, 4, 2>(A, W, bias, C, M, N, K, epi, st)
                                 : launch_gemm_ring_rect_epi<128, 64>(A, W, bias, C, M, N, K, epi, st);

@@ -1,7 +1,7 @@
 """Audit of the few-row GEMM dispatcher: for every GEMM of a vision block at 2 ... 12 frames' rows (and audio at 2 ... 8 segments, text at
 10 ... 40 questions) the dispatcher's choice against every named tile geometry, alone with COLD weights; prints the shapes where some
 geometry beats the choice by more than 5 %.  Candidates only: a rule is kept after an A/B in the forwards (tools/knob_ab_probe.py).
-usage: dispatch_audit_probe.py [out.json] [vision|audio|text]"""
+usage: dispatch_audit_probe.py [out.json] [vision|audio|text] [few]"""
 import json
 import sys
 
@@ -11,15 +11,16 @@ from probe_common import load_probe, event_ms
 
 L, lib = load_probe()
 EPI = {"bias": 0, "gelu": 1, "resid": 2}
-TILES = {"auto": -1, "db128": 0, "pp": 3, "ring128": 6, "ring64": 7, "ring64_k2": 11, "r128x64": 12, "r64x128": 13, "r128x128w8": 14, "r128x64w8": 15}
+TILES = {"auto": -1, "auto_tiled": -2, "sliver": 5, "ring32": 8, "ring32_k2": 9, "ring32_k4": 10, "db128": 0, "pp": 3, "ring128": 6, "ring64": 7, "ring64_k2": 11, "r128x64": 12, "r64x128": 13, "r128x128w8": 14, "r128x64w8": 15}
 st = L.stream_ptr()
 which = sys.argv[2] if len(sys.argv) > 2 else "vision"
+few = len(sys.argv) > 3 and sys.argv[3] == "few"            # the few-row end: one sample ... a handful
 if which == "vision":
-    D, rows_per, counts = 1280, 257, range(2, 13)
+    D, rows_per, counts = 1280, 257, ((1, 2) if few else range(2, 13))
 elif which == "audio":
-    D, rows_per, counts = 768, 687, range(2, 9)
+    D, rows_per, counts = 768, 687, ((1,) if few else range(2, 9))
 else:
-    D, rows_per, counts = 1024, 77, (10, 12, 14, 16, 20, 24, 28, 32, 40, 48)
+    D, rows_per, counts = 1024, 77, ((1, 2, 3, 4, 6, 9) if few else (10, 12, 14, 16, 20, 24, 28, 32, 40, 48))
 SHAPES = [("qkv", 3 * D, D, "bias"), ("fc1", 4 * D, D, "gelu"), ("out", D, D, "resid"), ("fc2", D, 4 * D, "resid")]
 rows = []
 for name, N, K, epi in SHAPES:
@@ -40,6 +41,10 @@ for name, N, K, epi in SHAPES:
                 if tag in ("ring64", "ring64_k2") and ((M + 63) // 64) * (N // 64) > 1100:
                     continue
                 if tag == "ring64_k2" and (K // 64) % 2:
+                    continue
+                if tag in ("sliver", "ring32", "ring32_k2", "ring32_k4") and (not few or ((M + 31) // 32) * (N // 32) > 2048):
+                    continue
+                if (tag == "ring32_k2" and (K // 64) % 2) or (tag == "ring32_k4" and (K // 64) % 4):
                     continue
 
                 def call():
