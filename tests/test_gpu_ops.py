@@ -86,6 +86,11 @@ def _dispatch_fuzz_shapes():
         shapes.append((M, int(rng.choice(Ns)), int(rng.choice(Ks)), int(rng.integers(0, 4))))
     # the ring tail peel: three frames' fc1 (7 x 40 ring tiles for 6 x 40 + 3 rows), four frames' qkv, and its limits (16 / 17 tail rows)
     shapes += [(771, 5120, 1280, 1), (1028, 3840, 1280, 0), (771, 5120, 256, 2), (768 + 16, 5120, 128, 3), (768 + 17, 5120, 128, 0)]
+    # the audit rules of round 5: 128 x 64 up to 700 rows (six questions' fc1, one segment's qkv) and up to 1536 rows for K = 5120 (four frames'
+    # fc2); 64 x 128 from 450 small tiles on (six frames' fc2 / out-proj, 24 questions' fc2); ping-pong for qkv from 80 tiles on
+    shapes += [(462, 4096, 1024, 1), (687, 2304, 768, 0), (700, 3072, 1024, 0), (701, 3072, 1024, 0), (1028, 1280, 5120, 2), (1536, 1280, 5120, 2),
+               (1537, 1280, 5120, 2), (1542, 1280, 5120, 2), (1542, 1280, 1280, 2), (1848, 1024, 4096, 2), (1694, 1024, 1024, 2),
+               (1285, 3840, 1280, 0), (1540, 3072, 1024, 0), (1028, 3840, 1280, 0), (1285, 5120, 1280, 1)]
     return shapes
 
 
