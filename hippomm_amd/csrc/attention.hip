@@ -23,6 +23,7 @@ namespace hmm {
 
 HMM_TUNABLE(int, g_attn_short_keys, 1)   // probe build: 0 = the text tower's 77 keys on the eight-tile instantiation (A/B, bit equality)
 HMM_TUNABLE(int, g_attn_q_split, 1)      // probe build: 0 = never split a (sample, head)'s queries over workgroups (A/B)
+HMM_TUNABLE(int, g_attn_q_split_wgs, 256) // the split is taken while twice the launch's workgroups are at most this many (512: 9-12 and 20-32 frames +2.4 ... +4.1 %)
 
 template <int DH, int NKT>
 __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
@@ -122,7 +123,7 @@ static int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int T, in
     // part stages the head's K and V itself: 82 KB from L2); same bits (attention_core.h).  Measured (tools/text_latency_probe.py):
     // one frame 2.46 -> 2.39 ms, one audio segment 0.712 -> 0.696; four parts are slower (2.63 ms), and so is any split of the
     // text tower's three query tiles (one question 1.04 -> 1.15 ms), hence T > 128.
-    const int q_parts = (g_attn_q_split && T > 128 && wgs * 2 <= kNumCU) ? 2 : 1;
+    const int q_parts = (g_attn_q_split && T > 128 && wgs * 2 <= g_attn_q_split_wgs) ? 2 : 1;
     kern<<<wgs * q_parts, kAttnWaves * 64, C::LDS, st>>>(qkv, out, batch, T, Lk, H, bias_k, bias_v, scale_log2e, causal ? 1 : 0, q_parts);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
