@@ -836,6 +836,7 @@ int gemm_set_small_tiles(int tiles) {
 HMM_TUNABLE(int, g_gemm_small_by_r128, 1) // probe build: 0 = the small-tile decision on the count of 256 x 256 tiles alone (round 4)
 HMM_TUNABLE(int, g_gemm_rect, 1)          // probe build: 0 = never the 128 x 64 ring tiles (A/B)
 HMM_TUNABLE(int, g_gemm_pp_bias_tiles, 80)    // see launch_gemm_small_epi; 0 = never
+HMM_TUNABLE(int, g_gemm_rect64_w8, 1)         // the 64 x 128 rule's tile with eight waves of 32 x 32 instead of four of 32 x 64 (6 frames -1.0 %, 24-26 questions -0.6 ... -1.3 %)
 HMM_TUNABLE(int, g_gemm_rect64_min_t64, 450) // launches of at least this many 64 x 64 tiles (and at most 256 tiles of 64 x 128) use 64 x 128 ring tiles; 0 = never
 HMM_TUNABLE(int, g_gemm_rect_rows, 700)        // row limit of the 128 x 64 rule (round 5: 320 with the four-wave tile; with eight waves it pays up to the few-row regime's 700 rows)
 HMM_TUNABLE(int, g_gemm_rect_rows_longk, 1536) // the 128 x 64 rule's row limit for K >= 5120 (fc2 of three to five frames: 20 column tiles x 7-11 row tiles); 0 = 320 as for every other GEMM
@@ -896,7 +897,8 @@ static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* 
         // -4 %); from 450 tiles on: at 432 (22 questions) it loses 3 % (profiles/r5_dispatch_audit_ab.json, LABNOTES_r5 17)
         if (g_gemm_rect64_min_t64 > 0 && !tail && (long)((M + 63) / 64) * (N / 64) >= g_gemm_rect64_min_t64 &&
             (long)((M + 63) / 64) * (N / 128) <= kNumCU)
-            return launch_gemm_ring_rect_epi<64, 128>(A, W, bias, C, M, N, K, epi, st);
+            return (g_gemm_ring8 && g_gemm_rect64_w8) ? launch_gemm_ring_rect_epi<64, 128, 2, 4>(A, W, bias, C, M, N, K, epi, st)
+                                                                        : launch_gemm_ring_rect_epi<64, 128>(A, W, bias, C, M, N, K, epi, st);
         // at most one 64x64 tile per CU: the deep-K ring (96 KiB, one workgroup per CU anyway) -- one frame's fc2 24.5 -> 21.9 us,
         // its out-proj 8.6 -> 8.0 (cold weights, tools/deepk_probe.py); with more tiles than CUs two plain-ring workgroups per CU win
         if (g_gemm_deepk && !tail && epi <= HMM_EPI_F32 && (K >> 6) % 2 == 0 && K >= 1024 && (long)((M + 63) / 64) * (N / 64) <= kNumCU)
@@ -974,6 +976,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         case HMM_GEMM_TILE_64x128_RING:   return launch_gemm_ring_rect_epi<64, 128>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_128x128_RING8: return launch_gemm_ring_rect_epi<128, 128, 2, 4>(A, W, bias, C, M, N, K, epi, st);
         case HMM_GEMM_TILE_128x64_RING8:  return launch_gemm_ring_rect_epi<128, 64, 4, 2>(A, W, bias, C, M, N, K, epi, st);
+        case HMM_GEMM_TILE_64x128_RING8:  return launch_gemm_ring_rect_epi<64, 128, 2, 4>(A, W, bias, C, M, N, K, epi, st);
 #ifdef HMM_PROBE
         // timing-only ablations of the eight-wave 128 x 128 ring (bias -> bf16 epilogue), five ring stages, and of the 64 x 64 ring
         case 101: return launch_gemm<128, 128, 2, 4, HMM_EPI_BIAS_BF16, 4, 1, 1>(A, W, bias, C, M, N, K, st);

@@ -280,6 +280,7 @@ int hmm_op_gemm_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const float* 
 #define HMM_GEMM_TILE_64x128_RING 13  /* 64 rows x 128 columns, 4 waves of 32 x 64, same ring */
 #define HMM_GEMM_TILE_128x128_RING8 14 /* 128x128 tiles behind the ring with EIGHT waves (64 x 32 each, two per SIMD) */
 #define HMM_GEMM_TILE_128x64_RING8  15 /* 128x64 tiles, eight waves of 32 x 32 */
+#define HMM_GEMM_TILE_64x128_RING8  16 /* 64x128 tiles, eight waves of 32 x 32 */
 #define HMM_GEMM_TILE_32x32_RING_K4 10  /* 32x32 tiles, 4 K-tiles per stage, 4 stages (128 KiB): few rows x a long K (one question's fc2); K % 256 == 0 */
 int hmm_op_gemm_bf16_tile(const uint16_t* a_dev, const uint16_t* w_dev, const float* bias_dev,
                           void* c_dev, int M, int N, int K, int epilogue, int tile, hmm_stream_t stream);

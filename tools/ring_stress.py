@@ -24,7 +24,7 @@ for M, N, K in shapes:
     for epi, dtype in ((2, torch.float32), (1, torch.bfloat16)):
         ref = x0.clone().to(dtype)
         L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), ref.data_ptr(), M, N, K, epi, 0, L.stream_ptr()), "ref")
-        for tile in (5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, -1):     # incl. round 5's 128x64 / 64x128 and eight-wave ring tiles
+        for tile in (5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, -1):     # incl. round 5's 128x64 / 64x128 and eight-wave ring tiles
             if tile in (9, 11) and (K // 64) % 2:
                 continue
             if tile == 10 and (K // 64) % 4:
