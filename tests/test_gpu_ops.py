@@ -139,7 +139,7 @@ def test_gemm_few_rows_sliver_kernel_bitwise_equal_to_the_tiled_kernels(M, N, K)
     for epi, dtype in ((EPI_BIAS_RESID_F32, torch.float32), (EPI_BIAS_GELU_BF16, torch.bfloat16), (EPI_BIAS_BF16, torch.bfloat16),
                        (EPI_F32, torch.float32)):
         outs = []
-        for variant in (0, 5, -1, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
+        for variant in (0, 5, -1, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16):
             c = c0.clone().to(dtype)
             L.check(lib.hmm_op_gemm_bf16_tile(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K, epi, variant,
                                               L.stream_ptr()), "gemm")
