@@ -1010,15 +1010,20 @@ int gemm_bf16_splitk(const bf16_t* A, const bf16_t* W, float* part, int M, int N
     if (g_gemm_splitk_tile >= 0) tile = g_gemm_splitk_tile;
     const int k_len = K / splits;
     if (tile < 0) {
-        // by the number of 64 x 64 workgroups (profiles/r5_splitk_probe.json, cold weights): under half a chip of them, 32 x 32
+        // by the number of 64 x 64 workgroups (profiles/r5_splitk_probe.json, cold weights): up to half a chip of them, 32 x 32
         // tiles put four times the workgroups to work (one question's fc2: 11.2 vs 14.3 us); up to one per CU, 64 x 64 tiles with
-        // two K-tiles per ring stage (one frame's fc2: 12.6 us, 22 unsplit); beyond that the plain rings
+        // two K-tiles per ring stage (one frame's fc2: 12.6 us, 22 unsplit); beyond that the plain rings;
         const long w64 = (long)((M + 63) / 64) * (N / 64) * splits;
         const bool k2 = k_len % 128 == 0;
-        if (w64 < 128) tile = k2 ? HMM_GEMM_TILE_32x32_RING_K2 : HMM_GEMM_TILE_32x32_RING;
+        // re-audited with the eight-wave tiles (profiles/r5_splitk_tile_audit.json, r5_splitk_rule2_ab.json): one question's 128 workgroups
+        // belong to the 32 x 32 tiles (6.8 vs 7.2 us; the question 0.982 -> 0.972 ms); past ~450 workgroups of 64 x 64 one round of
+        // 128 x 64 tiles (six questions 12.0 -> 10.9 us, -1.8 % in the forward; seven / eight questions would need two rounds: they keep
+        // 64 x 64), past 640 the eight-wave 128 x 128 tile (nine questions 16.2 -> 14.6 us, -1.3 %)
+        if (w64 <= 128) tile = k2 ? HMM_GEMM_TILE_32x32_RING_K2 : HMM_GEMM_TILE_32x32_RING;
         else if (w64 <= 256) tile = k2 ? HMM_GEMM_TILE_64x64_RING_K2 : HMM_GEMM_TILE_64x64_RING;
-        else if (w64 <= 1024) tile = HMM_GEMM_TILE_64x64_RING;
-        else tile = HMM_GEMM_TILE_128x128_RING;
+        else if (w64 > 448 && (long)((M + 127) / 128) * (N / 64) * splits <= kNumCU) tile = HMM_GEMM_TILE_128x64_RING;
+        else if (w64 > 640) tile = HMM_GEMM_TILE_128x128_RING8;
+        else tile = HMM_GEMM_TILE_64x64_RING;
     }
     t_gemm_splits = splits;
     int rc;
@@ -1031,6 +1036,9 @@ int gemm_bf16_splitk(const bf16_t* A, const bf16_t* W, float* part, int M, int N
         case HMM_GEMM_TILE_32x32_RING_K4: rc = launch_gemm<32, 32, 2, 2, HMM_EPI_F32, 4, 4>(A, W, nullptr, part, M, N, K, st); break;
         case HMM_GEMM_TILE_128x64_RING:   rc = launch_gemm<128, 64, 2, 2, HMM_EPI_F32, 4>(A, W, nullptr, part, M, N, K, st); break;
         case HMM_GEMM_TILE_64x128_RING:   rc = launch_gemm<64, 128, 2, 2, HMM_EPI_F32, 4>(A, W, nullptr, part, M, N, K, st); break;
+        case HMM_GEMM_TILE_128x128_RING8: rc = launch_gemm<128, 128, 2, 4, HMM_EPI_F32, 4>(A, W, nullptr, part, M, N, K, st); break;
+        case HMM_GEMM_TILE_128x64_RING8:  rc = launch_gemm<128, 64, 4, 2, HMM_EPI_F32, 4>(A, W, nullptr, part, M, N, K, st); break;
+        case HMM_GEMM_TILE_64x128_RING8:  rc = launch_gemm<64, 128, 2, 4, HMM_EPI_F32, 4>(A, W, nullptr, part, M, N, K, st); break;
         default:
             set_error("gemm_splitk: tile geometry %d has no split-K launch", tile);
             rc = HMM_E_INVALID;

@@ -292,7 +292,8 @@ def test_layernorm(rows, D):
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(77, 1024, 4096, 2), (257, 1280, 5120, 2), (514, 1280, 5120, 2), (687, 768, 3072, 2),
-                                           (77, 1024, 4096, 4), (300, 1280, 1280, 2), (40, 768, 3072, 8), (1030, 1280, 5120, 4)])
+                                           (77, 1024, 4096, 4), (300, 1280, 1280, 2), (40, 768, 3072, 8), (1030, 1280, 5120, 4),
+                                           (462, 1024, 4096, 4), (539, 1024, 4096, 4), (693, 1024, 4096, 4)])      # six / seven / nine questions: the 128-row split tiles
 def test_gemm_split_k_partials_and_the_layernorm_that_reduces_them(M, N, K, splits):
     """Few-row forwards run fc2 as a split-K launch: slab s = A[:, K_s] W[:, K_s]^T in fp32 (no bias), and the LayerNorm behind the
     GEMM adds the slabs in split order, the bias and the residual.  Checked: every slab against a torch fp32 product of the same
@@ -309,7 +310,7 @@ def test_gemm_split_k_partials_and_the_layernorm_that_reduces_them(M, N, K, spli
     kl = K // splits
     want_parts = torch.stack([a[:, s * kl:(s + 1) * kl].float() @ w[:, s * kl:(s + 1) * kl].float().T for s in range(splits)])
     slabs = {}
-    for tile in (-1, 6, 7, 8, 9, 10, 11, 12, 13):
+    for tile in (-1, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16):
         if tile in (9, 11) and kl % 128 or tile == 10 and kl % 256:
             continue
         part = torch.full((splits * M + 2, N), float("nan"), device="cuda")

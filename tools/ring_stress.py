@@ -47,7 +47,7 @@ for M, N, K in shapes:
             continue
         gam, bet = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
         ref_x = ref_y = None
-        for tile in (-1, 6, 7, 8, 11, 12, 13):
+        for tile in (-1, 6, 7, 8, 11, 12, 13, 14, 15, 16):
             diff = 0
             for r in range(REPS // 2):
                 if r % 2 == 0:
