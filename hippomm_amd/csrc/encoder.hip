@@ -358,6 +358,7 @@ extern "C" double hmm_encoder_flops_executed(const hmm_encoder* e, int batch) {
 }
 
 namespace hmm {
+HMM_TUNABLE(int, g_enc_text_head_fused, 1) // text head: EOS select + row gather + LayerNorm as one launch (probe build: 0 = the three kernels, A/B)
 HMM_TUNABLE(int, g_enc_cls_fork, 1)      // probe build: 0 = cls-row projection on the chain's own stream (A/B)
 HMM_TUNABLE(int, g_enc_fused_min_vision, 48) // frames of a forward from which in_proj + attention run as the fused kernel (round 5, profiles/r5_fused_min_ab2.json: projection GEMM + attention kernel 32 / 36 / 40 / 44 frames -2.3 / -2.2 / -3.6 / -1.3 %, equal at 48, +1 ... +4.6 % from 56 on)
 HMM_TUNABLE(int, g_enc_fused_min_audio, 9)   // clips (3 per segment) likewise: from three segments on (two segments 0.865 -> 0.839 ms unfused, three 0.936 vs 0.998; profiles/r5_fused_min_audio_ab.json)
@@ -385,7 +386,7 @@ static int chain_tokens(hmm_encoder* e, const Chain& c) {
     if (e->tower == HMM_TOWER_TEXT) {                  // ids (B,77) int64 -> token embedding + positions; EOS rows
         const int64_t* ids = static_cast<const int64_t*>(c.input);
         HMM_TRY(launch_embed_tokens(ids, e->tok_emb, e->pos, x, n_img * e->T, e->T, e->vocab, c.st));
-        HMM_TRY(launch_select_eos(ids, reinterpret_cast<int32_t*>(c.ws + p.off_sel), n_img, e->T, c.st));
+        if (!g_enc_text_head_fused) HMM_TRY(launch_select_eos(ids, reinterpret_cast<int32_t*>(c.ws + p.off_sel), n_img, e->T, c.st));
         return HMM_OK;
     }
     if (e->tower == HMM_TOWER_VISION) HMM_TRY(launch_im2col_vision(static_cast<const float*>(c.input), im2col, n_img, c.st));
@@ -503,10 +504,16 @@ static int chain_head(hmm_encoder* e, const Chain& c) {
     float* xc = reinterpret_cast<float*>(c.ws + p.off_xc);
     bf16_t* hl = reinterpret_cast<bf16_t*>(c.ws + p.off_hl);
     float* hv = reinterpret_cast<float*>(c.ws + p.off_hv);
-    if (e->tower == HMM_TOWER_TEXT)                    // SelectEOSAndProject: the row at the EOS position of each sample
-        HMM_TRY(launch_gather_selected_rows(chain_x(c), reinterpret_cast<const int32_t*>(c.ws + p.off_sel), e->T, xc,
-                                            p.n_img, e->D * 4, c.st));
-    HMM_TRY(launch_layernorm_bf16(xc, (size_t)e->D, e->head_g, e->head_b, hl, p.n_img, e->D, 1e-6f, c.st));
+    if (e->tower == HMM_TOWER_TEXT && g_enc_text_head_fused) {
+        // SelectEOSAndProject: the row at the EOS position of each sample, LayerNormed -- one launch instead of three
+        HMM_TRY(launch_layernorm_eos_bf16(chain_x(c), static_cast<const int64_t*>(c.input), e->T, e->head_g, e->head_b, hl, p.n_img, e->D,
+                                          1e-6f, c.st));
+    } else {
+        if (e->tower == HMM_TOWER_TEXT)
+            HMM_TRY(launch_gather_selected_rows(chain_x(c), reinterpret_cast<const int32_t*>(c.ws + p.off_sel), e->T, xc,
+                                                p.n_img, e->D * 4, c.st));
+        HMM_TRY(launch_layernorm_bf16(xc, (size_t)e->D, e->head_g, e->head_b, hl, p.n_img, e->D, 1e-6f, c.st));
+    }
     HMM_TRY(gemm_bf16(hl, e->head_w, nullptr, hv, p.n_img, HMM_FEATURE_DIM, e->D, HMM_EPI_F32, c.tile, c.st));
     HMM_TRY(launch_l2norm_rows(hv, c.out, c.batch, e->clips, e->log_scale, c.st));
     return HMM_OK;

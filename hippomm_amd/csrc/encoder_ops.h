@@ -31,6 +31,9 @@ int launch_gather_rows(const void* src, size_t src_row_stride_bytes, void* dst, 
 int launch_embed_tokens(const int64_t* ids, const float* table, const float* pos, float* x, int n_rows, int T, int vocab,
                         hipStream_t st);
 int launch_select_eos(const int64_t* ids, int32_t* sel, int batch, int T, hipStream_t st);
+// y_bf16[b] = LN(x[b*T + first position of the largest id of sample b]): the text head's select + gather + LayerNorm in one launch
+int launch_layernorm_eos_bf16(const float* x, const int64_t* ids, int T, const float* g, const float* b, bf16_t* y, int batch, int D,
+                              float eps, hipStream_t st);
 int launch_gather_selected_rows(const void* src, const int32_t* sel, int T, void* dst, int n_rows, int row_bytes,
                                 hipStream_t st);
 int launch_cast_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t st);

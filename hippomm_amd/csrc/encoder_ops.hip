@@ -268,6 +268,42 @@ __global__ __launch_bounds__(64) void select_eos_kernel(const int64_t* __restric
     if (lane == 0) sel[b] = pos;
 }
 
+// Text head in ONE launch (was select_eos + gather_selected_rows + layernorm_bf16: three kernels at the launch floor each):
+// y_bf16[b] = LN(x_f32[b*T + eos(b)]) with eos(b) = the first position of the largest token id of sample b.  One wave per sample;
+// the same argmax as select_eos_kernel and the same row_layernorm as layernorm_bf16_kernel: same bits.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_eos_bf16_kernel(const float* __restrict__ x, const int64_t* __restrict__ ids, int T,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 bf16_t* __restrict__ y, int batch, float eps) {
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    int64_t best = INT64_MIN;
+    int pos = 0x7FFFFFFF;
+    for (int t = lane; t < T; t += 64) {
+        const int64_t v = ids[(size_t)b * T + t];
+        if (v > best) { best = v; pos = t; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int64_t ob = __shfl_xor(best, off, 64);
+        const int op = __shfl_xor(pos, off, 64);
+        if (ob > best || (ob == best && op < pos)) { best = ob; pos = op; }
+    }
+    const float* src = x + ((size_t)b * T + pos) * D;
+    float4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const float4*>(src + 4 * (64 * j + lane));
+    row_layernorm<NV>(v, gamma, beta, eps, lane);
+    bf16_t* dst = y + (size_t)b * D;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        bf16x4 o = {(bf16_t)v[j].x, (bf16_t)v[j].y, (bf16_t)v[j].z, (bf16_t)v[j].w};
+        *reinterpret_cast<bf16x4*>(dst + 4 * (64 * j + lane)) = o;
+    }
+}
+
 // dst[b] = src[(b*T + sel[b])]   rows of row_bytes (16-B pieces)
 __global__ void gather_selected_rows_kernel(const char* __restrict__ src, const int32_t* __restrict__ sel, int T,
                                             char* __restrict__ dst, int n_rows, int row_bytes) {
@@ -373,6 +409,18 @@ int launch_embed_tokens(const int64_t* ids, const float* table, const float* pos
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
+int launch_layernorm_eos_bf16(const float* x, const int64_t* ids, int T, const float* g, const float* b, bf16_t* y, int batch, int D,
+                              float eps, hipStream_t st) {
+    HMM_REQUIRE(D == 768 || D == 1024 || D == 1280, HMM_E_INVALID, "layernorm_eos: D must be 768, 1024 or 1280, got %d", D);
+    if (batch <= 0) return HMM_OK;
+    const int blocks = (batch + 3) / 4;
+    if (D == 768)       layernorm_eos_bf16_kernel<3><<<blocks, 256, 0, st>>>(x, ids, T, g, b, y, batch, eps);
+    else if (D == 1024) layernorm_eos_bf16_kernel<4><<<blocks, 256, 0, st>>>(x, ids, T, g, b, y, batch, eps);
+    else                layernorm_eos_bf16_kernel<5><<<blocks, 256, 0, st>>>(x, ids, T, g, b, y, batch, eps);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+
 int launch_select_eos(const int64_t* ids, int32_t* sel, int batch, int T, hipStream_t st) {
     select_eos_kernel<<<batch, 64, 0, st>>>(ids, sel, T);
     HMM_LAUNCH_CHECK();
