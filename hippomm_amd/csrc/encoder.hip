@@ -29,6 +29,7 @@ HMM_TUNABLE(int, g_enc_split_min, 13)    // frames of a vision forward from whic
 HMM_TUNABLE(int, g_enc_split_min_text, 54)  // the same for the text tower: 54 questions = 4158 rows is where one chain's launches cross 16 row tiles of 256 (54 ... 62 questions 4.76 ... 5.28 -> 4.14 ... 4.50 ms as two chains; 24 ... 52 questions 8 ... 13 % slower as two; profiles/r5_split_min_text_ab.json)
 HMM_TUNABLE(int, g_enc_two_chain_small_tiles, 64)  // gemm_set_small_tiles of a two-chain forward
 HMM_TUNABLE(int, g_enc_split_min_audio, 12) // the audio tower's smaller kernels overlap from 4 segments on (-7 .. -11 %; tools/split_min_probe.py)
+HMM_TUNABLE(int, g_enc_audio_one_round, 1) // see split_point
 HMM_TUNABLE(int, g_enc_split_num, 128)   // frames of 256 that go to the first of the two chains
 // Few-row forwards (one frame, one question, one audio segment -- the reference's own call sizes, hippocampal_memory.py:1222,
 // :2173, :2445): fc2 walks K = 4D on few tiles, i.e. a chain of latencies on a mostly idle chip (one frame: 100 tiles of 64 x 64
@@ -318,6 +319,10 @@ namespace hmm {
 static int split_point(const hmm_encoder* e, int batch) {
     const int split_min = e->tower == HMM_TOWER_AUDIO ? g_enc_split_min_audio : e->tower == HMM_TOWER_VISION ? g_enc_split_min : g_enc_split_min_text;
     if (e->streams < 2 || batch * e->clips < split_min) return 0;
+    // audio, 5-7 segments (15-21 clips): the whole forward's fused in_proj + attention launch is ONE round of the chip (clips x 12
+    // heads <= 256 workgroups), and one chain beats two half-rounds: 1.238 / 1.329 / 1.465 -> 1.200 / 1.251 / 1.285 ms
+    // (profiles/r5_audio_chains_ab.json); at 4 segments two chains still win (1.143 vs 1.175), from 8 on the launch is two rounds
+    if (e->tower == HMM_TOWER_AUDIO && g_enc_audio_one_round && batch * e->clips > split_min && batch * e->clips * e->heads <= kNumCU) return 0;
     const int b0 = (int)((long)batch * g_enc_split_num / 256);     // probe build: uneven halves (tile-round quantisation A/B)
     return b0 < 1 ? 1 : (b0 >= batch ? batch - 1 : b0);
 }

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
     const bf16_t* __restrict__ a /* [n_img*T][D] LayerNorm output */, const bf16_t* __restrict__ w /* [3D][D] */,
     const float* __restrict__ bias /* [3D] */, const bf16_t* __restrict__ qkv_cls /* [n_img][3D], CLS_OUTSIDE only */,
     bf16_t* __restrict__ out /* [n_img*T][D] */, int n_img, float scale_log2e,
-    const float* __restrict__ bias_k /* [D], BIAS_KV only */, const float* __restrict__ bias_v HMM_FUSED_PROBE_ARG) {
+    const float* __restrict__ bias_k /* [D], BIAS_KV only */, const float* __restrict__ bias_v, int even_map HMM_FUSED_PROBE_ARG) {
     using P = FusedPlan<G>;
     using Cfg = typename P::Cfg;
     constexpr int kD = G::D, kH = G::H, kDH = G::DH, kT = G::T;
@@ -76,10 +76,19 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int n = blockIdx.x >> 3;
-    const int b_lin = (blockIdx.x & 7) + 8 * (n / kH);
-    const int h = n % kH;
-    if (b_lin >= n_img) return;
+    // XCD x (= blockIdx % 8) takes a contiguous run of the (sample, head) list, sample-major: a sample's heads share its LayerNorm rows
+    // through one L2, and the workgroups are spread evenly -- with the earlier "sample i on XCD i % 8" 18 clips put 36 workgroups on two
+    // XCDs of 32 CUs each and the launch took two rounds (one chain of six audio segments: 44.5 -> 25 us per block).
+    const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7;
+    const int pair = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    int b_lin = pair / kH;
+    int h = pair % kH;
+    if (!even_map) {                                   // probe build A/B: the earlier mapping (grid padded to 8 samples x heads)
+        const int n = blockIdx.x >> 3;
+        b_lin = (blockIdx.x & 7) + 8 * (n / kH);
+        h = n % kH;
+        if (b_lin >= n_img) return;
+    }
     const int b = n_img - 1 - b_lin;
     HMM_FSTAMP(0, __builtin_amdgcn_s_memrealtime())
     HMM_FSTAMP(6, __builtin_amdgcn_s_memtime())
@@ -192,15 +201,16 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(
     HMM_FSTAMP(8, __builtin_amdgcn_s_memtime())
 }
 
+HMM_TUNABLE(int, g_fused_even_map, 1)   // probe build: 0 = sample i on XCD i % 8 with a padded grid (the mapping before round 5's audio fix)
 template <class G>
 static int launch_fused(const bf16_t* a, const bf16_t* w, const float* bias, const bf16_t* qkv_cls, bf16_t* out, int n_img,
                         hipStream_t st, const float* bias_k, const float* bias_v) {
     HMM_REQUIRE(n_img >= 1 && (int64_t)n_img * G::T * G::D < (1ll << 31), HMM_E_INVALID, "qkv_attention: n_img=%d out of range", n_img);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)G::DH);
-    const int grid = 8 * ((n_img + 7) / 8) * G::H;
+    const int grid = g_fused_even_map ? n_img * G::H : 8 * ((n_img + 7) / 8) * G::H;
     auto kern = qkv_attention_kernel<G>;
     HMM_ENSURE_DYN_LDS(kern, FusedPlan<G>::Lds);
-    kern<<<grid, 512, FusedPlan<G>::Lds, st>>>(a, w, bias, qkv_cls, out, n_img, scale_log2e, bias_k, bias_v HMM_FUSED_PROBE_VAL);
+    kern<<<grid, 512, FusedPlan<G>::Lds, st>>>(a, w, bias, qkv_cls, out, n_img, scale_log2e, bias_k, bias_v, g_fused_even_map HMM_FUSED_PROBE_VAL);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }

@@ -200,7 +200,7 @@ double hmm_encoder_flops(const hmm_encoder* enc, int batch);
 /* FLOPs this build actually executes for the same forward: temporal taps of the Conv3d folded into one K-padded matrix,
  * and the last block computed for the selected row only (vision / audio: K,V for every token, the rest for token 0). */
 double hmm_encoder_flops_executed(const hmm_encoder* enc, int batch);
-/* n_streams = 2 (default): from 13 frames / 4 audio segments / 54 questions on, a forward runs as two half-batches, the second on a stream owned
+/* n_streams = 2 (default): from 13 frames / 4 audio segments (except 5-7, whose fused attention launch is one round of the chip) / 54 questions on, a forward runs as two half-batches, the second on a stream owned
  * by the handle (forked from / joined to the caller's stream with events).  n_streams = 1: one chain on the caller's
  * stream only.  Embeddings are bitwise identical either way (tests/test_gpu_encoder_batch.py). */
 int  hmm_encoder_set_streams(hmm_encoder* enc, int n_streams);
