@@ -23,12 +23,13 @@ namespace hmm {
 
 HMM_TUNABLE(int, g_attn_short_keys, 1)   // probe build: 0 = the text tower's 77 keys on the eight-tile instantiation (A/B, bit equality)
 HMM_TUNABLE(int, g_attn_q_split, 1)      // probe build: 0 = never split a (sample, head)'s queries over workgroups (A/B)
+HMM_TUNABLE(int, g_attn_even_map, 1)    // the (sample, head) list in eight equal contiguous runs, one per XCD, no padding workgroups (as qkv_attention.hip): 20 / 28 / 36 frames -1.1 / -0.7 / -0.8 %; the text tower (T = 77) keeps sample i on XCD i % 8 (+0.3 ... +0.6 % with the even map; profiles/r5_attn_even_map_ab.json)
 HMM_TUNABLE(int, g_attn_q_split_wgs, 256) // the split is taken while twice the launch's workgroups are at most this many (512: 9-12 and 20-32 frames +2.4 ... +4.1 %)
 
 template <int DH, int NKT>
 __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n_img, int T, int Lk, int H,
-    const float* __restrict__ bias_k, const float* __restrict__ bias_v, float scale_log2e, int causal, int q_parts) {
+    const float* __restrict__ bias_k, const float* __restrict__ bias_v, float scale_log2e, int causal, int q_parts, int even_map) {
     using C = AttnCfg<DH, NKT>;
     constexpr int NT = kAttnWaves * 64;
     constexpr int CPR = DH / 8;                      // 16-B chunks per K/V row
@@ -48,10 +49,18 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(
     // q_parts > 1 (few samples): consecutive blocks are the query parts of one (sample, head)
     const int q_part = blockIdx.x % q_parts;
     const int blk = blockIdx.x / q_parts;
-    const int n = blk >> 3;
-    const int b_lin = (blk & 7) + 8 * (n / H);
-    const int h = n % H;
-    if (b_lin >= n_img) return;
+    int b_lin, h;
+    if (even_map) {                                      // q_parts == 1, grid = n_img x H: eight contiguous, equally long runs of the
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7;     // (sample, head) list, one per XCD (qkv_attention.hip)
+        const int pair = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+        b_lin = pair / H;
+        h = pair % H;
+    } else {
+        const int n = blk >> 3;
+        b_lin = (blk & 7) + 8 * (n / H);
+        h = n % H;
+        if (b_lin >= n_img) return;
+    }
     const int b = n_img - 1 - b_lin;
     const int D = H * DH;
     const size_t row_stride = (size_t)3 * D;
@@ -124,7 +133,9 @@ static int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int T, in
     // one frame 2.46 -> 2.39 ms, one audio segment 0.712 -> 0.696; four parts are slower (2.63 ms), and so is any split of the
     // text tower's three query tiles (one question 1.04 -> 1.15 ms), hence T > 128.
     const int q_parts = (g_attn_q_split && T > 128 && wgs * 2 <= g_attn_q_split_wgs) ? 2 : 1;
-    kern<<<wgs * q_parts, kAttnWaves * 64, C::LDS, st>>>(qkv, out, batch, T, Lk, H, bias_k, bias_v, scale_log2e, causal ? 1 : 0, q_parts);
+    const int even_map = g_attn_even_map && q_parts == 1 && T > 128;
+    kern<<<even_map ? batch * H : wgs * q_parts, kAttnWaves * 64, C::LDS, st>>>(qkv, out, batch, T, Lk, H, bias_k, bias_v, scale_log2e, causal ? 1 : 0,
+                                                                                 q_parts, even_map);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
