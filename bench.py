@@ -58,7 +58,8 @@ FRAMES_PER_GPU = 256           # cfg2
 CFG5_FRAMES = 3600             # cfg5: one hour at 1 fps
 SCENE_LEN = 6                  # frames per synthetic scene
 SCAN_ROWS, SCAN_K = 1_000_000, 32
-LAUNCH_TIMEOUT_S = 1500.0      # wall-clock limit of a self-launched multi-rank run (HMM_BENCH_LAUNCH_TIMEOUT_S overrides)
+LAUNCH_TIMEOUT_S = 840.0       # wall-clock limit of a self-launched multi-rank run, below the outer `timeout 900` of tools/runs/*.sh
+                               # (HMM_BENCH_LAUNCH_TIMEOUT_S overrides)
 SCAN_WARM_MS = 60.0            # every scan leg is timed in steady state: see event_time_ms
 # Rehearsal of the N > 1 code path on a box with fewer GPUs (HMM_BENCH_REHEARSAL=1): every rank uses cuda:0 and the
 # collectives run over gloo.  Exercises launch, sharding, gathers, merges and the JSON line -- NOT RCCL, and the
@@ -112,23 +113,36 @@ def launch_ranks(n: int, argv) -> int:
     # collective, a rendezvous that never completes) the whole group is killed and the run fails loudly instead of hanging the
     # box.  Nothing here re-executes a process that has touched the GPU: the parent never has, the children are new.
     limit = float(os.environ.get("HMM_BENCH_LAUNCH_TIMEOUT_S", LAUNCH_TIMEOUT_S))
+    import signal
+
+    def kill_group(proc):
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                return
+            try:
+                proc.wait(timeout=grace)
+                return
+            except subprocess.TimeoutExpired:
+                continue
+
+    def on_term(signum, _frame):                              # an outer `timeout` / the driver ends the parent: take the ranks along
+        raise KeyboardInterrupt(f"signal {signum}")
+    old_term = signal.signal(signal.SIGTERM, on_term)
     proc = subprocess.Popen(cmd, env=env, start_new_session=True)
     try:
         return proc.wait(timeout=limit)
     except subprocess.TimeoutExpired:
         print(f"bench.py: the {n} ranks did not finish within {limit:.0f} s; killing their process group", file=sys.stderr)
-        import signal
-        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
-            try:
-                os.killpg(proc.pid, sig)
-            except ProcessLookupError:
-                break
-            try:
-                proc.wait(timeout=grace)
-                break
-            except subprocess.TimeoutExpired:
-                continue
         return 5
+    except BaseException as exc:                              # Ctrl-C, SIGTERM, anything: the ranks live in their own session and
+        print(f"bench.py: interrupted ({exc!r}); killing the ranks' process group", file=sys.stderr)      # would otherwise keep the GPUs
+        return 130
+    finally:
+        if proc.poll() is None:
+            kill_group(proc)
+        signal.signal(signal.SIGTERM, old_term)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -675,6 +689,212 @@ def call_size_bench():
     return out
 
 
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def write_synthetic_jpegs(folder: str, n: int, h: int = 720, w: int = 1280, quality: int = 90):
+    """n frames of the synthetic video as JPEG files (scene-structured like synthetic_frames: a low-frequency pattern per scene
+    of SCENE_LEN frames plus per-frame sensor noise of sigma 4 grey levels), generated on the GPU, encoded by Pillow on the
+    host's threads.  Returns (paths in time order, mean file size in bytes)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from hippomm_amd.preprocess import decode_workers
+    g = torch.Generator(device="cuda")
+    frames = []
+    scene, scene_id = None, -1
+    for i in range(n):
+        sid = i // SCENE_LEN
+        if sid != scene_id:
+            g.manual_seed(1000 + sid)
+            base = torch.randn(1, 3, 6, 8, generator=g, device="cuda")
+            scene = torch.nn.functional.interpolate(base, size=(h, w), mode="bicubic", align_corners=False)[0] * 50.0 + 128.0
+            scene_id = sid
+        g.manual_seed(7_000_000 + i)
+        frame = scene + 4.0 * torch.randn(3, h, w, generator=g, device="cuda")
+        frames.append(frame.clamp_(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy())
+    paths = [os.path.join(folder, f"video_00_{i:05d}.jpg") for i in range(n)]
+    with ThreadPoolExecutor(max_workers=min(32, decode_workers())) as pool:
+        list(pool.map(lambda a: Image.fromarray(a[0]).save(a[1], quality=quality), zip(frames, paths)))
+    return paths, sum(os.path.getsize(p) for p in paths) / n
+
+
+def formation_bench(do_cpu):
+    """The reference's REAL formation call (hippocampal_memory.py:1180-1186, :1328-1335): JPEG paths in, embeddings out on the
+    host -- `extract_features({'vision': paths}, ['vision'])['vision'].detach().cpu().numpy()` -- for the 32-frame buffer and for
+    256 frames of 1280x720, whole call by wall clock, beside the stages timed alone and the tensor-in forward of the same size."""
+    import shutil
+    import tempfile
+    from hippomm_amd import preprocess as pp
+    from hippomm_amd.encoder import ImageBind, synthetic_state_dict
+    folder = tempfile.mkdtemp(prefix="hmm_frames_")
+    out = {"what": "extract_features({'vision': [paths]}, ['vision'])['vision'].detach().cpu().numpy() on 1280x720 JPEG files "
+                   "(quality 90, synthetic scenes + sensor noise), wall clock of the whole call, median of 7 after 2 warm calls; "
+                   "stages: each timed ALONE (median of 3), in the pipeline they overlap",
+           "host_threads_decode": pp.decode_workers(), "host_cpu_quota": pp.cpu_quota(),
+           "bound": "a range of few frames is latency-bound on the tower (~2.7 ms + 0.29 ms per frame), so a call cut into k ranges costs "
+                    "~2.7 (k - 1) ms over the tensor-in forward plus the decode of its first range; the host decodes ~6 frames/ms on its "
+                    "threads (one interpreter lock), about 1.8x the tower's rate, which gives 3-4 ranges for 256 frames"}
+    try:
+        paths, mean_bytes = write_synthetic_jpegs(folder, 256)
+        out["jpeg_mean_bytes"] = int(mean_bytes)
+        model = ImageBind(state_dict=synthetic_state_dict(("vision",), seed=1234), towers=("vision",))
+        tower = model.model.towers["vision"]
+        call = lambda ps: model.extract_features({"vision": ps}, ["vision"])["vision"].detach().cpu().numpy()
+        one = []
+        for _ in range(3):                                        # one frame on one thread: the unit of the decode bound
+            t0 = time.perf_counter()
+            pp.decode_rgb(paths[:8], workers=1)
+            one.append((time.perf_counter() - t0) / 8 * 1e3)
+        out["decode_ms_per_frame_one_thread"] = round(_median(one), 3)
+        for n in (32, 256):
+            ps = paths[:n]
+            call(ps); call(ps)
+            t, stats = [], {}
+            for _ in range(7):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                emb_files = call(ps)
+                t.append((time.perf_counter() - t0) * 1e3)
+            emb = torch.empty(n, 1024, device="cuda")
+            pp.vision_pipeline(ps, "cuda", lambda x, lo, hi: tower.forward_into(x[lo:hi], emb[lo:hi]), stats=stats)
+            torch.cuda.synchronize()
+            # the stages alone
+            load = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                x = pp.load_and_transform_vision_data_device(ps, "cuda")      # decode | upload | resize, no tower
+                torch.cuda.synchronize()
+                load.append((time.perf_counter() - t0) * 1e3)
+            dec = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                frames = pp.decode_rgb(ps)
+                dec.append((time.perf_counter() - t0) * 1e3)
+            wx, wy, ww, wh = pp.needed_window(720, 1280)
+            pinned = torch.empty(n, wh, ww, 3, dtype=torch.uint8, pin_memory=True)
+            np_view = pinned.numpy()
+            for i, f in enumerate(frames):
+                np_view[i] = f[wy:wy + wh, wx:wx + ww]
+            del frames
+            dev_u8 = torch.empty(n, wh, ww, 3, dtype=torch.uint8, device="cuda")
+            h2d_ms = event_time_ms(lambda: dev_u8.copy_(pinned, non_blocking=True), 3, warmup=1)
+            resize_ms = event_time_ms(lambda: pp._preprocess_into(dev_u8, x, (720, 1280)), 3, warmup=1)
+            fwd_ms = event_time_ms(lambda: tower.forward_into(x, emb), 5, warmup=2)
+            same = bool(torch.equal(emb.cpu(), torch.from_numpy(emb_files)))
+            d2h = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                emb.detach().cpu().numpy()
+                d2h.append((time.perf_counter() - t0) * 1e3)
+            ms = _median(t)
+            rec = {"ms_end_to_end": round(ms, 3), "frames_per_s": round(n / ms * 1e3, 1),
+                   "ms_tensor_in_forward": round(fwd_ms, 3), "frames_per_s_tensor_in": round(n / fwd_ms * 1e3, 1),
+                   "ratio_to_tensor_in": round(fwd_ms / ms, 3), "ms_over_tensor_in": round(ms - fwd_ms, 3),
+                   "stages_alone_ms": {"files_to_preprocessed_tensors": round(_median(load), 3),
+                                       "decode_to_arrays_all_threads": round(_median(dec), 3),
+                                       "h2d_pinned_needed_window": round(h2d_ms, 3), "resize_crop_normalise": round(resize_ms, 3),
+                                       "forward": round(fwd_ms, 3), "d2h_embeddings": round(_median(d2h), 3)},
+                   "pipeline": {"ranges_issued": stats.get("chunks"), "decode_threads": stats.get("workers"),
+                                "pinned_ring_frames": stats.get("ring_frames"), "uploaded_window_xywh": list(stats.get("window", ())),
+                                "uploaded_bytes_per_frame": int(ww * wh * 3)},
+                   "decode_cpu_ms_all_frames": round(n * out["decode_ms_per_frame_one_thread"], 1),
+                   "embeddings_equal_tensor_in_forward_bitwise": same}
+            out[f"paths_{n}"] = rec
+            del pinned, dev_u8, x, emb
+        if do_cpu:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from host_vision_pipeline import load_and_transform_vision_data
+            load_and_transform_vision_data(paths[:2], "cpu")
+            t0 = time.perf_counter()
+            ref = load_and_transform_vision_data(paths[:32], "cpu")
+            dt = time.perf_counter() - t0
+            got = pp.load_and_transform_vision_data_device(paths[:32], "cuda").cpu()
+            out["cpu_baseline"] = {"value": round(32 / dt, 1), "unit": "frames/s (files -> normalised (3,224,224) tensors; no encoder)",
+                                   "ms_per_frame": round(dt / 32 * 1e3, 2), "cores": 1, "kind": "port",
+                                   "sample": "the reference's host chain restated (tests/host_vision_pipeline.py: Pillow decode, BICUBIC "
+                                             "resize, centre crop, ToTensor, Normalize) on the first 32 files, one thread as upstream runs it"}
+            out["preprocessed_tensors_equal_host_chain_bitwise"] = bool(torch.equal(got, ref))
+        del model, tower
+    finally:
+        shutil.rmtree(folder, ignore_errors=True)
+        torch.cuda.empty_cache()
+    return out
+
+
+def audio_bench():
+    """The reference's real audio call (hippocampal_memory.py:1219-1225): one 10-second 16 kHz wav path in, one embedding out on the
+    host; and 16 files in one call.  Whole call by wall clock, the stages timed alone beside it."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from scipy.io import wavfile
+    from hippomm_amd import preprocess as pp
+    from hippomm_amd.encoder import ImageBind, synthetic_state_dict
+    folder = tempfile.mkdtemp(prefix="hmm_wav_")
+    out = {"what": "extract_features({'audio': [wav paths]}, ['audio'])['audio'].detach().cpu().numpy() on 10-second 16 kHz float32 "
+                   "wav files (as hippocampal_memory.py:1219 writes them), wall clock of the whole call, median of 15 after 3 warm calls"}
+    try:
+        rng = np.random.default_rng(11)
+        paths = []
+        for i in range(16):
+            p = os.path.join(folder, f"segment_{i:02d}.wav")
+            wavfile.write(p, 16000, (rng.standard_normal(160000) * 0.1).astype(np.float32))
+            paths.append(p)
+        model = ImageBind(state_dict=synthetic_state_dict(("audio",), seed=1234), towers=("audio",))
+        tower = model.model.towers["audio"]
+        call = lambda ps: model.extract_features({"audio": ps}, ["audio"])["audio"].detach().cpu().numpy()
+        for n in (1, 16):
+            ps = paths[:n]
+            for _ in range(3):
+                call(ps)
+            t = []
+            for _ in range(15):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                call(ps)
+                t.append((time.perf_counter() - t0) * 1e3)
+            rd, sl = [], []
+            for _ in range(15):
+                t0 = time.perf_counter()
+                raw = [pp._read_wav_raw(p) for p in ps]
+                rd.append((time.perf_counter() - t0) * 1e3)
+                t0 = time.perf_counter()
+                clips = [d[s:e] for d, _ in raw for s, e in pp.audio_clip_bounds(d.shape[0])]
+                buf = np.empty((len(clips), 32000), dtype=np.float32)
+                for r, c in enumerate(clips):
+                    pp._pcm_to_float(c, buf[r])
+                sl.append((time.perf_counter() - t0) * 1e3)
+            mel = pp.load_and_transform_audio_data_device(ps, "cuda")
+            host_clips = torch.from_numpy(buf).pin_memory()
+            dev_clips = torch.empty_like(host_clips, device="cuda")
+            h2d_ms = event_time_ms(lambda: dev_clips.copy_(host_clips, non_blocking=True), 20, warmup=3)
+            fbank_ms = event_time_ms(lambda: pp.melspec_clips_device(dev_clips), 20, warmup=3)
+            emb = torch.empty(n, 1024, device="cuda")
+            tower_ms = event_time_ms(lambda: tower.forward_into(mel, emb), 20, warmup=3)
+            load_ms = []
+            for _ in range(15):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pp.load_and_transform_audio_data_device(ps, "cuda")
+                torch.cuda.synchronize()
+                load_ms.append((time.perf_counter() - t0) * 1e3)
+            ms = _median(t)
+            out[f"wav_{n}"] = {"ms_end_to_end": round(ms, 3), "ms_tower_tensor_in": round(tower_ms, 3),
+                               "ms_over_tower": round(ms - tower_ms, 3), "ms_load_data_alone_synced": round(_median(load_ms), 3),
+                               "stages_alone_ms": {"wav_read": round(_median(rd), 3), "clip_slicing_into_buffer": round(_median(sl), 3),
+                                                   "h2d_pinned": round(h2d_ms, 4), "fbank": round(fbank_ms, 4),
+                                                   "tower": round(tower_ms, 3)}}
+        del model, tower
+    finally:
+        shutil.rmtree(folder, ignore_errors=True)
+        torch.cuda.empty_cache()
+    return out
+
+
 def encoder_cpu_baseline(frames32: torch.Tensor):
     """the fp32 oracle tower on this host's cores, batch 32 (processing.frame_buffer_size),
     median of 3 passes."""
@@ -989,6 +1209,8 @@ def main():
                 line["joint_vision_audio"] = joint_bench()
                 line["reference_call_sizes"] = call_size_bench()
                 line["consolidation"] = consolidation_bench(do_cpu=not args.no_cpu_baseline)
+                line["formation_from_files"] = formation_bench(do_cpu=not args.no_cpu_baseline)
+                line["audio_from_wav"] = audio_bench()
             if not args.no_cpu_baseline:
                 line["torch_rocm_reference"] = torch_rocm_reference()
                 line["cpu_baseline"] = encoder_cpu_baseline(frames32)

@@ -44,6 +44,8 @@ _SIGNATURES = {
     "hmm_preprocess_vision_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "hmm_preprocess_vision_u8": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, C.c_int, c_ptr, c_ptr, C.c_int,
                                            C.c_int, C.c_int, c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "hmm_host_rgbx_to_rgb": (C.c_int, [c_ptr, C.c_size_t, c_ptr]),
+    "hmm_host_arrow_rgbx_to_rgb": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     "hmm_audio_fbank_workspace_bytes": (C.c_size_t, [C.c_int]),
     "hmm_audio_fbank": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int64, c_ptr, c_ptr, C.c_float, C.c_float, c_ptr, c_ptr,
                                   C.c_size_t, c_ptr]),

@@ -328,14 +328,26 @@ static int split_point(const hmm_encoder* e, int batch) {
 }
 }  // namespace hmm
 
-extern "C" size_t hmm_encoder_workspace_bytes(const hmm_encoder* e, int batch) {
-    if (!e || batch < 1) return 0;
+static size_t workspace_bytes_exact(const hmm_encoder* e, int batch) {
     const int b0 = split_point(e, batch);
     const int sk = splitk_mode(e, batch);
     const size_t one = ws_plan(e, batch, sk).total;
     if (b0 == 0) return one;
     const size_t two = ws_plan(e, b0, sk).total + ws_plan(e, batch - b0, sk).total;
     return two > one ? two : one;            // a forward under stream capture runs as one chain (see hmm_encoder_forward)
+}
+
+// What a forward of `batch` samples needs, and never less than a smaller batch needs: the few-row regime adds fp32 split-K slabs
+// (a text forward of 9 questions uses more than one of 10), so a caller that sizes its workspace once for its largest batch can
+// run every smaller one.  The regime ends at a handful of samples; the loop below is a few iterations.
+extern "C" size_t hmm_encoder_workspace_bytes(const hmm_encoder* e, int batch) {
+    if (!e || batch < 1) return 0;
+    size_t need = workspace_bytes_exact(e, batch);
+    for (int b = 1; b < batch && splitk_mode(e, b); ++b) {
+        const size_t s = workspace_bytes_exact(e, b);
+        if (s > need) need = s;
+    }
+    return need;
 }
 
 extern "C" double hmm_encoder_flops(const hmm_encoder* e, int batch) {
@@ -540,7 +552,7 @@ extern "C" int hmm_encoder_forward(hmm_encoder* e, const void* input_dev, int ba
         e->ready = true;
     }
     HMM_REQUIRE((int64_t)batch * e->clips * e->T < (1ll << 31) / 8, HMM_E_INVALID, "encoder_forward: batch too large");
-    const size_t need = hmm_encoder_workspace_bytes(e, batch);
+    const size_t need = workspace_bytes_exact(e, batch);
     HMM_REQUIRE(workspace_bytes >= need, HMM_E_WORKSPACE, "encoder_forward: workspace %zu < required %zu",
                 workspace_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);

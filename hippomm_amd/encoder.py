@@ -333,6 +333,37 @@ class ImageBind(nn.Module):
             embeddings = self.model(inputs)
         return embeddings
 
+    def _vision_from_files(self, images) -> torch.Tensor:
+        """Image paths -> (B,1024) embeddings as ONE pipeline: the host decodes while the GPU uploads, resizes and already
+        embeds the frames that are ready (hippomm_amd.preprocess.vision_pipeline).  Same bits as forward(load_data(...)):
+        every range the tower sees has at least two frames unless the call has one, and the tower's embedding of a frame
+        does not depend on the batch it rides in within that regime (tests/test_gpu_encoder_batch.py)."""
+        from .preprocess import vision_pipeline
+        paths = [img if isinstance(img, str) else img.filename for img in images]
+        tower = self.model.towers[ModalityType.VISION]
+        step = int(self.model.max_batch.get(ModalityType.VISION, 256))
+        emb = torch.empty(len(paths), 1024, dtype=torch.float32, device=self.device)
+
+        def embed(x, lo, hi):
+            for s in range(lo, hi, step):
+                tower.forward_into(x[s:min(s + step, hi)], emb[s:min(s + step, hi)])
+
+        vision_pipeline(paths, self.device, embed, max_chunk=step)
+        return emb
+
     def extract_features(self, inputs, modalities):
-        """load_data + forward (reference :135-151)."""
-        return self.forward(self.load_data(inputs, modalities))
+        """load_data + forward (reference :135-151).  Vision given as files (the reference's formation calls,
+        hippocampal_memory.py:1180-1186, :1328-1335) runs decode, upload, resize and the tower as one overlapped pipeline;
+        a failure is logged and the modality left out, exactly as load_data does (:110-112)."""
+        fused = {}
+        rest = list(modalities)
+        v = ModalityType.VISION
+        if v in rest and v in inputs and not isinstance(inputs[v], torch.Tensor) and v in self.model.towers:
+            rest.remove(v)
+            try:
+                with torch.no_grad():
+                    fused[v] = self._vision_from_files(inputs[v])
+            except Exception as e:  # noqa: BLE001 - mirror of the reference's catch-all
+                logger.error(f"Error processing {v}: {str(e)}")
+        out = self.forward(self.load_data(inputs, rest)) if rest else {}
+        return {m: (fused[m] if m in fused else out[m]) for m in modalities if m in fused or m in out}

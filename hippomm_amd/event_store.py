@@ -75,21 +75,31 @@ def event_json_text(event: Any, fast: bool = True) -> str:
     return text
 
 
+def _host_library():
+    """The library for its HOST-side JSON routines, or None when it is not built / too old: reading and saving an event file is
+    plain host work and keeps working on json alone (the GPU paths have no such fallback and raise)."""
+    from . import _lib as L
+    try:
+        return L.load()
+    except (L.HippoMMHipError, AttributeError, OSError):
+        return None
+
+
 def _matrix_text(rows, native: bool = True) -> str:
     """``json.dumps(rows, indent=2)`` of a non-empty list of equally long lists of floats whose closing bracket sits at indent 4.
     ``native``: written by the library (``hmm_json_write_matrix_f64``: float.__repr__ digits and notation, byte for byte --
     tests/test_cpu_event_store.py); otherwise row by row with the C encoder of ``json`` and re-indented."""
-    if native:
+    lib = _host_library() if native else None
+    if lib is not None:
         import ctypes as C
         from . import _lib as L
-        lib = L.load()
         m = np.array(rows, dtype=np.float64)
         cap = lib.hmm_json_matrix_text_bound(m.shape[0], m.shape[1], 4)
         buf = C.create_string_buffer(cap)
         n = C.c_size_t(0)
         L.check(lib.hmm_json_write_matrix_f64(m.ctypes.data_as(C.c_void_p), m.shape[0], m.shape[1], 4, C.cast(buf, C.c_void_p), cap, C.byref(n)),
                 "hmm_json_write_matrix_f64")
-        return buf.raw[:n.value].decode("ascii")
+        return C.string_at(buf, n.value).decode("ascii")          # only the written bytes (buf.raw would copy the whole bound first)
     body = ",\n".join("      [\n        " + json.dumps(r)[1:-1].replace(", ", ",\n        ") + "\n      ]" for r in rows)
     return "[\n" + body + "\n    ]"
 
@@ -166,7 +176,9 @@ def _load_json_native(raw: bytes):
     does not expect one -- the caller then uses plain ``json.loads``."""
     import ctypes as C
     from . import _lib as L
-    lib = L.load()
+    lib = _host_library()
+    if lib is None:
+        return None
 
     class Span(C.Structure):
         _fields_ = [("begin", C.c_size_t), ("end", C.c_size_t), ("rows", C.c_size_t), ("cols", C.c_size_t)]

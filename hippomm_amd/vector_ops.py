@@ -97,7 +97,10 @@ class FeatureStore:
         counter, which the searches check: the shadow is then rebuilt before it is used.  Writes that bypass torch (a raw
         kernel on ``rows.data_ptr()``) need ``invalidate_shadow()`` or ``build_shadow(force=True)``.  The build is enqueued
         on the current stream; searches on another stream must be ordered after it by the caller."""
-        version = getattr(self.rows, "_version", 0)
+        try:
+            version = self.rows._version
+        except (RuntimeError, AttributeError):       # an inference tensor tracks no version: a snapshot until invalidate_shadow()
+            version = 0
         if force or getattr(self, "_shadow", None) is None or getattr(self, "_shadow_version", version) != version:
             lib = _lib.load()
             n = len(self)

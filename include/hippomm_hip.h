@@ -183,6 +183,8 @@ int  hmm_encoder_load_param(hmm_encoder* enc, const char* upstream_key,
 /* Number of parameters still missing (0 = ready); names via hmm_last_error() when > 0. */
 int  hmm_encoder_missing_params(hmm_encoder* enc);
 
+/* Workspace of a forward of `batch` samples.  Non-decreasing in `batch`: a workspace sized for the largest batch a caller will
+ * ever pass serves every smaller one (the few-sample forwards keep fp32 split-K slabs that slightly larger batches do not). */
 size_t hmm_encoder_workspace_bytes(const hmm_encoder* enc, int batch);
 /* input_dev: vision (batch,3,224,224) fp32 | audio (batch,3,1,128,204) fp32 | text (batch,77) int64
  * out_dev:   (batch,1024) fp32
@@ -226,6 +228,19 @@ int    hmm_preprocess_vision_u8(const uint8_t* frames_dev, int batch, int in_h, 
                                 const int32_t* kv_dev, const int32_t* bv_dev, int ksize_v,
                                 int row_first, int row_last, float* out_dev,
                                 void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
+
+/* Host-side hand-over of one frame decoded by Pillow to the (pinned) upload buffer of hmm_preprocess_vision_u8 -- the step
+ * between Image.open(path).convert("RGB") and the transform chain in imagebind.data.load_and_transform_vision_data [upstream,
+ * recalled] (hippomm/models/foundation_models.py:87-90).  No GPU call.  Pillow stores RGB as 4 bytes per pixel (R,G,B,pad);
+ * src_rgbx: n_pixels * 4 bytes; dst_rgb: n_pixels * 3 bytes, nothing beyond them is written.  The _arrow_ form takes the
+ * `struct ArrowArray*` inside the "arrow_array" capsule of Image.__arrow_c_array__() (Arrow C data interface:
+ * fixed_size_list<uint8>[4] with width * height entries; HMM_E_INVALID on any other layout) and copies the window
+ * [y0, y0 + roi_h) x [x0, x0 + roi_w) as a dense (roi_h, roi_w, 3) block: only the pixels the centre crop's resampling taps
+ * touch have to cross PCIe (57 % of a 1280x720 frame).  Called through ctypes these run without the interpreter lock, which
+ * is what lets the decode threads of hippomm_amd/preprocess.py scale. */
+int hmm_host_rgbx_to_rgb(const uint8_t* src_rgbx, size_t n_pixels, uint8_t* dst_rgb);
+int hmm_host_arrow_rgbx_to_rgb(const void* arrow_array, int width, int height, int x0, int y0, int roi_w, int roi_h,
+                               uint8_t* dst_rgb);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side audio front end.  Replaces waveform2melspec + Normalize inside

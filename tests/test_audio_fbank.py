@@ -313,3 +313,33 @@ def test_imagebind_load_data_accepts_wav_paths(tmp_path):
     # an unreadable file: logged and skipped like any per-modality failure (:110-112)
     (tmp_path / "bad.wav").write_bytes(b"not a wav file")
     assert "audio" not in model.load_data({"audio": [str(tmp_path / "bad.wav")]}, ["audio"])
+
+
+@pytest.mark.gpu
+def test_wav_paths_fast_path_equals_clip_by_clip(tmp_path):
+    """load_and_transform_audio_data_device: samples as stored -> pinned buffer -> one upload -> one launch writing the
+    (B,3,1,128,204) result in place.  Bitwise equal to the fbank of every clip launched on its own, for float32 and int16 files,
+    stereo, and a call that mixes a file shorter than a clip with full-length ones (the grouped route)."""
+    from scipy.io import wavfile
+    from hippomm_amd.preprocess import (audio_clip_bounds, load_and_transform_audio_data_device, melspec_clips_device, read_wav)
+    rng = np.random.default_rng(21)
+    files = {"a_f32.wav": (rng.standard_normal(160000) * 0.1).astype(np.float32),
+             "b_i16.wav": (rng.standard_normal(112345) * 3000).astype(np.int16),
+             "c_stereo_i16.wav": (rng.standard_normal((48000, 2)) * 3000).astype(np.int16),
+             "d_short.wav": (rng.standard_normal(20000) * 0.1).astype(np.float32)}
+    for name, x in files.items():
+        wavfile.write(tmp_path / name, 16000, x)
+
+    def clip_by_clip(names):
+        rows = []
+        for name in names:
+            w, rate = read_wav(str(tmp_path / name))
+            assert rate == 16000
+            for s, e in audio_clip_bounds(w.shape[1]):
+                rows.append(melspec_clips_device(torch.from_numpy(w[0, s:e].copy())[None].cuda())[0])
+        return torch.stack(rows).view(len(names), 3, 1, 128, 204)
+
+    for names in (["a_f32.wav"], ["b_i16.wav", "a_f32.wav", "c_stereo_i16.wav"], ["a_f32.wav", "d_short.wav", "b_i16.wav"]):
+        for _ in range(2):                                       # the second call reuses the pinned buffer
+            got = load_and_transform_audio_data_device([str(tmp_path / n) for n in names], torch.device("cuda"))
+            assert got.shape == (len(names), 3, 1, 128, 204) and torch.equal(got, clip_by_clip(names)), names

@@ -175,3 +175,43 @@ def test_self_launch_kills_ranks_that_hang(monkeypatch, tmp_path, capsys):
         time.sleep(0.1)
     else:
         raise AssertionError("a grandchild of the killed launch is still alive")
+
+
+def test_self_launch_takes_the_ranks_along_when_the_parent_is_terminated(tmp_path):
+    """The ranks run in a session of their own, so a SIGTERM to the parent (an outer `timeout`, the driver) does not reach them
+    by itself: launch_ranks turns it into an exception and kills the group on every way out."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    marker = tmp_path / "rank.pid"
+    hang = tmp_path / "hang.py"
+    hang.write_text(f"import os, time\nopen({str(marker)!r}, 'w').write(str(os.getpid()))\ntime.sleep(600)\n")
+    parent = tmp_path / "parent.py"
+    parent.write_text("import os, sys\n"
+                      f"sys.path.insert(0, {str(Path(__file__).resolve().parent.parent)!r})\n"
+                      "os.environ['HMM_BENCH_REHEARSAL'] = '1'\n"
+                      "import bench\n"
+                      "real = bench.subprocess.Popen\n"
+                      f"bench.subprocess.Popen = lambda cmd, **kw: real([sys.executable, {str(hang)!r}], **kw)\n"
+                      "sys.exit(bench.launch_ranks(2, ['--gpus', '2']))\n")
+    p = subprocess.Popen([sys.executable, str(parent)], stderr=subprocess.PIPE, text=True)
+    for _ in range(600):
+        if marker.exists() and marker.read_text():
+            break
+        time.sleep(0.1)
+    else:
+        p.kill()
+        raise AssertionError("the stand-in rank never started")
+    p.send_signal(signal.SIGTERM)
+    _, err = p.communicate(timeout=60)
+    assert p.returncode == 130 and "killing the ranks' process group" in err
+    pid = int(marker.read_text())
+    for _ in range(100):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("the rank outlived its terminated parent")

@@ -288,3 +288,23 @@ def test_native_matrix_writer_is_json_dumps_indent_2_byte_for_byte():
         m = v[: (len(v) // 64) * 64].reshape(-1, 64)
         assert es._matrix_text(m.tolist(), native=True) == want(m) == es._matrix_text(m.tolist(), native=False)
     assert es._matrix_text([[0.5]], native=True) == want(np.array([[0.5]]))
+
+
+def test_event_files_are_read_and_written_without_the_library(tmp_path, monkeypatch):
+    """Reading and saving an event is host work: with libhippomm_hip.so missing (or stale) the json route answers, same bytes and
+    same values -- only the GPU paths refuse to run without the library."""
+    from hippomm_amd import _lib, event_store as es
+    rng = np.random.default_rng(8)
+    feats = rng.standard_normal((40, 1024)).astype(np.float32)
+    event = {"features": {"vision": feats, "vision_times": np.arange(40.0)}, "frames": [], "frame_times": [], "frame_captions": [],
+             "audio_times": [], "audio_transcription": [], "holistic_audio_transcription": [], "summary": "s", "start_time": 0.0,
+             "end_time": 39.0}
+    with_lib = es.save_event(event, tmp_path / "a" / "ev.json", write_sidecars=False).read_bytes()
+
+    def missing():
+        raise _lib.HippoMMHipError("libhippomm_hip.so is missing")
+    monkeypatch.setattr(_lib, "load", missing)
+    without = es.save_event(event, tmp_path / "b" / "ev.json", write_sidecars=False).read_bytes()
+    assert without == with_lib
+    got, _ = es.parse_event_features(tmp_path / "b" / "ev.json")
+    assert np.array_equal(got["vision"], feats)

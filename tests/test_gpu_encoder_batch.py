@@ -262,3 +262,22 @@ def test_forward_is_graph_capturable(batch, streams):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, tower(x))
+
+
+@pytest.mark.parametrize("tower", ["vision", "audio", "text"])
+def test_workspace_bytes_never_shrink_with_the_batch(tower):
+    """hmm_encoder_workspace_bytes is non-decreasing in the batch (the few-sample forwards keep split-K slabs that the next larger
+    batch does not), so a C caller that sizes its workspace once for its largest batch can run every smaller one."""
+    from hippomm_amd.encoder import HipTower, synthetic_state_dict
+    t = HipTower(tower, synthetic_state_dict((tower,), depth={tower: 1}), depth=1)
+    sizes = [t._lib.hmm_encoder_workspace_bytes(t._h, b) for b in range(1, 70)]
+    assert all(a <= b for a, b in zip(sizes, sizes[1:])), sizes[:16]
+    big = torch.empty(sizes[-1], dtype=torch.uint8, device="cuda")
+    from hippomm_amd.encoder import INPUT_SHAPE, INPUT_DTYPE
+    for b in (1, 2, 9, 10, 11):
+        x = torch.zeros(b, *INPUT_SHAPE[tower], dtype=INPUT_DTYPE[tower], device="cuda")
+        if tower == "text":
+            x[:, 0], x[:, 5] = 49406, 49407
+        out = torch.empty(b, 1024, device="cuda")
+        assert t._lib.hmm_encoder_forward(t._h, x.data_ptr(), b, out.data_ptr(), big.data_ptr(), big.numel(), None) == 0
+    torch.cuda.synchronize()

@@ -182,3 +182,24 @@ def test_frames_on_disk_to_a_consolidated_event_and_back_to_a_query(tmp_path):
         if (r == 0 or gaps_ok[r - 1]) and gaps_ok[r]:
             assert idx[r] == w_idx[r]
     np.testing.assert_allclose(full[idx], sims, rtol=0, atol=2e-6)                    # every hit carries its own similarity
+
+
+def test_extract_features_from_files_equals_forward_of_load_data_bitwise(tmp_path):
+    """The overlapped files -> embeddings pipeline behind extract_features (decode | upload + resize | tower, cut into ranges by
+    the timing of the decoders) gives the bits of the two-step route forward(load_data(...)) (foundation_models.py:135-151), for
+    one frame, a segment, the 32-frame buffer and a call that mixes both frame sizes; a failing file leaves the modality out."""
+    from hippomm_amd.encoder import ImageBind
+    paths, _ = _write_frames(tmp_path)
+    vspec = ib.reduced(ib.VISION_HUGE, DEPTH)
+    model = ImageBind(state_dict=ib.synthetic_state(vspec, seed=77, init="rich"), towers=("vision",), depth={"vision": DEPTH})
+    for sel in (paths[:1], paths[:8], paths[:32], paths[4:40:3], paths):
+        fused = model.extract_features({"vision": sel}, ["vision"])["vision"]
+        two_step = model.forward(model.load_data({"vision": sel}, ["vision"]))["vision"]
+        assert fused.shape == (len(sel), 1024) and torch.equal(fused, two_step)
+    class _Img:                                                  # PIL images are accepted through .filename (:83-86)
+        def __init__(self, filename):
+            self.filename = filename
+    assert torch.equal(model.extract_features({"vision": [_Img(p) for p in paths[:8]]}, ["vision"])["vision"],
+                       model.extract_features({"vision": paths[:8]}, ["vision"])["vision"])
+    assert model.extract_features({"vision": paths[:3] + [str(tmp_path / "nope.jpg")]}, ["vision"]) == {}
+    assert "vision" in model.extract_features({"vision": paths[:3]}, ["vision"])             # and the next call works

@@ -278,3 +278,18 @@ def test_shadow_follows_in_place_updates_of_the_rows():
     assert store._shadow is None
     i2, s2 = store.search_device(q, 8)
     assert torch.equal(i2, ie) and torch.equal(s2.view(torch.int32), se.view(torch.int32))
+
+
+def test_shadow_of_a_store_created_under_inference_mode():
+    """An inference tensor tracks no version counter (reading ._version raises RuntimeError, not AttributeError): such a store is a
+    snapshot until invalidate_shadow(), and the prefiltered searches work on it."""
+    from hippomm_amd.vector_ops import FeatureStore
+    with torch.inference_mode():
+        g = torch.Generator(device="cuda").manual_seed(3)
+        rows = torch.randn(20000, 1024, generator=g, device="cuda")
+        q = torch.randn(1024, generator=g, device="cuda")
+        store = FeatureStore(rows)
+        store.build_shadow()
+        i0, s0 = store.search_device(q, 5)
+        i1, s1 = store.search_prefiltered_device(q, 5)
+    assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
