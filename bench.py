@@ -871,10 +871,10 @@ def audio_bench():
             mel = pp.load_and_transform_audio_data_device(ps, "cuda")
             host_clips = torch.from_numpy(buf).pin_memory()
             dev_clips = torch.empty_like(host_clips, device="cuda")
-            h2d_ms = event_time_ms(lambda: dev_clips.copy_(host_clips, non_blocking=True), 20, warmup=3)
-            fbank_ms = event_time_ms(lambda: pp.melspec_clips_device(dev_clips), 20, warmup=3)
+            h2d_ms = event_time_ms(lambda: dev_clips.copy_(host_clips, non_blocking=True), 20, warmup=3, warm_ms=20.0)
+            fbank_ms = event_time_ms(lambda: pp.melspec_clips_device(dev_clips), 20, warmup=3, warm_ms=20.0)
             emb = torch.empty(n, 1024, device="cuda")
-            tower_ms = event_time_ms(lambda: tower.forward_into(mel, emb), 20, warmup=3)
+            tower_ms = event_time_ms(lambda: tower.forward_into(mel, emb), 20, warmup=3, warm_ms=SCAN_WARM_MS)   # steady clocks, as every sub-ms leg
             load_ms = []
             for _ in range(15):
                 torch.cuda.synchronize()

@@ -14,6 +14,7 @@
 //     stores 8 B (bf16) / 16 B (fp32) per lane instead of 2 B.
 //   - tile order is remapped so that the blocks that land on one XCD (blockIdx % 8) walk
 //     neighbouring tiles and share A / W panels in that XCD's L2.
+#include <string>
 #include <type_traits>
 #include "hmm_common.h"
 #include "encoder_ops.h"
@@ -658,6 +659,63 @@ static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void
     return HMM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The few-row dispatcher's rules, as data.  Every threshold of launch_gemm_small_epi / gemm_bf16 below is one row here: the
+// constant's name (probe build: the run-time knob hmm_probe_set_<name>), the shipped limit, the value that switches the rule
+// OFF, what it decides, the forwards on which it fires ("tower:batch,batch;...") and the measurement it came from.  FROZEN in
+// round 6: no new rules.  `python tools/dispatch_audit_probe.py --check` re-times every row (rule on / off on its own forwards,
+// interleaved in one process, bit equality checked) and writes profiles/r6_dispatch_recheck.json; a row that does not buy 2 %
+// on any of its forwards on that run is deleted, not re-tuned.
+struct DispatchRule { const char* knob; int limit; int off; const char* what; const char* forwards; const char* evidence; };
+constexpr DispatchRule kDispatchRules[] = {
+    {"g_gemm_small_64", 512, 0, "launches of at most this many 64x64 tiles run on them behind the 4-deep ring (else 128x128 ring / double buffer)",
+     "text:1,4;vision:1,2;audio:1", "r3_sliver_probe.json, r3_text_latency.json"},
+    {"g_gemm_small_32", 400, 0, "launches of at most this many 32x32 tiles run on them (one 16x16 block per wave)",
+     "text:1,2;vision:1", "r3_text_latency.json"},
+    {"g_gemm_deepk", 1, 0, "deep-K rings: 2 / 4 K-tiles per stage while most CUs have a workgroup of their own (32x32: <= 192 / 256 tiles, 64x64: <= 256)",
+     "text:1,2;vision:1", "r4_deepk_probe.json"},
+    {"g_gemm_ring8", 1, 0, "the 128-row ring tiles (128x128, 128x64) with eight waves instead of four",
+     "vision:1,8;audio:1;text:9", "r5_rect_tile_probe2.json, r5_ring8_ab.json"},
+    {"g_gemm_rect", 1, 0, "128x64 ring tiles when 64x64 tiles outnumber the CUs but 128x64 tiles do not, up to g_gemm_rect_rows rows",
+     "vision:1;text:4,6;audio:1", "r5_rect_tile_probe.json, r5_rect_forward2.json"},
+    {"g_gemm_rect_rows", 700, 320, "row limit of the 128x64 rule (320 = the four-wave tile's)",
+     "text:5,6,7,8;audio:1", "r5_rect700_ab.json"},
+    {"g_gemm_rect_rows_longk", 1536, 0, "the 128x64 rule's row limit for K >= 5120 (fc2 of three to five frames)",
+     "vision:3,4,5", "r5_rect_longk_ab.json"},
+    {"g_gemm_rect64_min_t64", 450, 0, "64x128 ring tiles from this many 64x64 tiles on, while 64x128 tiles do not outnumber the CUs",
+     "vision:6;text:24,26", "r5_dispatch_audit_ab.json"},
+    {"g_gemm_ring_peel_rows", 16, 0, "a last row tile of at most this many rows is peeled off a ring launch that it pushes past one tile per CU",
+     "vision:3,4", "r5_ring_peel_ab_vision.json"},
+    {"g_gemm_small_by_r128", 1, 0, "a launch of at most one 128x128 tile per CU is a small launch whatever its count of 256x256 tiles",
+     "vision:12,24", "r5_small_by_r128_ab.json"},
+};
+constexpr bool rule_name_is(const char* a, const char* b) {
+    while (*a && *a == *b) { ++a; ++b; }
+    return *a == *b;
+}
+constexpr int rule_limit(const char* knob) {
+    for (const DispatchRule& r : kDispatchRules)
+        if (rule_name_is(r.knob, knob)) return r.limit;
+    return -0x7fffffff;                                    // a misspelt name shows up as an absurd threshold in every test
+}
+#define HMM_RULE(name) HMM_TUNABLE(int, name, rule_limit(#name))
+#ifdef HMM_PROBE
+// the table as JSON, for tools/dispatch_audit_probe.py --check
+extern "C" const char* hmm_probe_dispatch_rules() {
+    static std::string text;
+    if (text.empty()) {
+        text = "[";
+        for (const DispatchRule& r : kDispatchRules) {
+            if (text.size() > 1) text += ", ";
+            text += std::string("{\"knob\": \"") + r.knob + "\", \"limit\": " + std::to_string(r.limit) + ", \"off\": " + std::to_string(r.off) +
+                    ", \"what\": \"" + r.what + "\", \"forwards\": \"" + r.forwards + "\", \"evidence\": \"" + r.evidence + "\"}";
+        }
+        text += "]";
+    }
+    return text.c_str();
+}
+#endif
+
 // Rows per wave of the sliver kernel (16 MT) and whether it beats the tiled kernels, from two fitted lines
 // (tools/sliver_probe.py, profiles/r3_sliver_probe.json): a wave reads its fragments from L2 unshared, so the kernel moves
 // waves x K x (MT + 1) x 32 B at ~7.5 TB/s chip-wide (less when fewer than ~192 waves are in flight) after ~3 us of launch and
@@ -666,9 +724,9 @@ static int launch_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void
 // one or two dozen rows and for the text tower's fc2 at 77 rows (13 vs 15 us).
 HMM_TUNABLE(int, g_gemm_sliver_mt, 0)    // probe build: force 16 / 32 / 64 rows per wave (1 / 2 / 4)
 HMM_TUNABLE(int, g_gemm_sliver_auto, 1)  // probe build: 0 = the dispatcher never picks the sliver kernel
-HMM_TUNABLE(int, g_gemm_small_64, 512)   // launches of at most this many 64x64 tiles use them (behind the ring); 0 = never
-HMM_TUNABLE(int, g_gemm_small_32, 400)   // launches of at most this many 32x32 tiles use them (behind the ring); 0 = never
-HMM_TUNABLE(int, g_gemm_deepk, 1)        // probe build: 0 = never the deep-K rings (A/B)
+HMM_RULE(g_gemm_small_64)
+HMM_RULE(g_gemm_small_32)
+HMM_RULE(g_gemm_deepk)
 static bool ring32_fits(int M, int N) { return g_gemm_small_32 && (long)((M + 31) / 32) * (N / 32) <= g_gemm_small_32; }
 static float sliver_us(int M, int N, int K, int mt) {
     const long waves = (long)((M + 16 * mt - 1) / (16 * mt)) * (N / 16);
@@ -814,7 +872,7 @@ static int launch_gemm_ring128_epi(const bf16_t* A, const bf16_t* W, const float
 // 32 x 32, two waves per SIMD): one wave's LDS reads and DMA issue run under its partner's MFMAs.  Alone with cold weights
 // (profiles/r5_rect_tile_probe2.json) 128 x 128: 17.1 -> 15.2 us (one frame's qkv), 13.3 -> 11.9 (one audio segment's fc1),
 // 53.4 -> 46.8 (eight frames' fc2); 128 x 64: 12.2 -> 11.5, 13.0 -> 11.9.  Same MFMA sequence per output element: same bits.
-HMM_TUNABLE(int, g_gemm_ring8, 1)          // probe build: 0 = the four-wave instantiations (A/B)
+HMM_RULE(g_gemm_ring8)
 static int launch_gemm_ring128_auto_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                                         int epi, hipStream_t st) {
     return g_gemm_ring8 ? launch_gemm_ring_rect_epi<128, 128, 2, 4>(A, W, bias, C, M, N, K, epi, st)
@@ -833,15 +891,12 @@ int gemm_set_small_tiles(int tiles) {
     t_gemm_small_tiles = tiles;
     return prev;
 }
-HMM_TUNABLE(int, g_gemm_small_by_r128, 1) // probe build: 0 = the small-tile decision on the count of 256 x 256 tiles alone (round 4)
-HMM_TUNABLE(int, g_gemm_rect, 1)          // probe build: 0 = never the 128 x 64 ring tiles (A/B)
-HMM_TUNABLE(int, g_gemm_pp_bias_tiles, 80)    // see launch_gemm_small_epi; 0 = never
-HMM_TUNABLE(int, g_gemm_rect64_w8, 1)         // the 64 x 128 rule's tile with eight waves of 32 x 32 instead of four of 32 x 64 (6 frames -1.0 %, 24-26 questions -0.6 ... -1.3 %)
-HMM_TUNABLE(int, g_gemm_rect64_min_t64, 450) // launches of at least this many 64 x 64 tiles (and at most 256 tiles of 64 x 128) use 64 x 128 ring tiles; 0 = never
-HMM_TUNABLE(int, g_gemm_rect_rows, 700)        // row limit of the 128 x 64 rule (round 5: 320 with the four-wave tile; with eight waves it pays up to the few-row regime's 700 rows)
-HMM_TUNABLE(int, g_gemm_rect_rows_longk, 1536) // the 128 x 64 rule's row limit for K >= 5120 (fc2 of three to five frames: 20 column tiles x 7-11 row tiles); 0 = 320 as for every other GEMM
-HMM_TUNABLE(int, g_gemm_tail_64, 128)      // the peeled last row tile of a big launch uses 64x64 tiles up to this many of them
-HMM_TUNABLE(int, g_gemm_ring_peel_rows, 16) // a last row tile of at most this many rows is peeled off a ring launch that it pushes past one tile per CU; 0 = never
+HMM_RULE(g_gemm_small_by_r128)
+HMM_RULE(g_gemm_rect)
+HMM_RULE(g_gemm_rect64_min_t64)
+HMM_RULE(g_gemm_rect_rows)
+HMM_RULE(g_gemm_rect_rows_longk)
+HMM_RULE(g_gemm_ring_peel_rows)
 static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K,
                                  int epi, hipStream_t st, bool tail = false) {
     if (g_gemm_small_stages != 2 && !tail && g_gemm_ring_peel_rows > 0) {
@@ -861,11 +916,9 @@ static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* 
         }
     }
     if (g_gemm_small_stages == 2 || (long)((M + 127) / 128) * (N / 128) > 256) {
-        // past one ring tile per CU.  With the plain bias -> bf16 epilogue (qkv) the ping-pong tile already wins from ~80 tiles on
-        // (five to seven frames' qkv: 90-120 tiles, 25.4-25.7 us against 27.2-28.3); with the GELU epilogue (fc1) it does not
-        if (g_gemm_pp_bias_tiles > 0 && !tail && epi == HMM_EPI_BIAS_BF16 && N % 256 == 0 && K % 128 == 0 &&
-            (long)((M + 255) / 256) * (N / 256) >= g_gemm_pp_bias_tiles && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31))
-            return launch_gemm_pp<HMM_EPI_BIAS_BF16>(A, W, bias, C, M, N, K, st);
+        // past one ring tile per CU: the double-buffered 128 x 128 kernel, two per CU.  (Round 5 sent bias -> bf16 launches of at least
+        // 80 ping-pong tiles to the 256 x 256 kernel here: +0.3 ... 0.5 % on five to seven frames in round 6's recheck, below the 2 % a
+        // rule has to buy -- removed, profiles/r6_dispatch_recheck_midround.json.)
         return launch_gemm_epi<128, 128, 2, 2>(A, W, bias, C, M, N, K, epi, st);
     }
     if (!tail && epi <= HMM_EPI_F32 && ring32_fits(M, N)) {
@@ -876,8 +929,9 @@ static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* 
         if (g_gemm_deepk && K >= 1024 && (K >> 6) % 2 == 0 && t32 <= 192) return launch_gemm_ringk_epi<32, 4, 2>(A, W, bias, C, M, N, K, epi, st);
         return launch_gemm_ring32_epi(A, W, bias, C, M, N, K, epi, st);
     }
-    if (g_gemm_small_64 &&
-        (long)((M + 63) / 64) * (N / 64) <= (tail ? g_gemm_tail_64 : g_gemm_small_64)) {
+    // (the peeled last row tile of a big launch used to take 64 x 64 tiles up to 128 of them: 0.0 % at 128 / 256 frames in round 6's
+    // recheck -- removed; it runs on the 128 x 128 ring like any launch of few tiles)
+    if (g_gemm_small_64 && !tail && (long)((M + 63) / 64) * (N / 64) <= g_gemm_small_64) {
         // a few hundred rows with more 64 x 64 tiles than CUs, but at most one 128 x 64 tile per CU: nobody runs two workgroups one
         // after (or beside) the other -- one frame's qkv / fc1 (300 / 400 tiles -> 180 / 240) 13.9 -> 12.1 us / 15.0 -> 13.0 us
         // alone with cold weights (profiles/r5_rect_tile_probe.json), one frame's forward 2.24 -> 2.12 ms, four questions
@@ -897,8 +951,7 @@ static int launch_gemm_small_epi(const bf16_t* A, const bf16_t* W, const float* 
         // -4 %); from 450 tiles on: at 432 (22 questions) it loses 3 % (profiles/r5_dispatch_audit_ab.json, LABNOTES_r5 17)
         if (g_gemm_rect64_min_t64 > 0 && !tail && (long)((M + 63) / 64) * (N / 64) >= g_gemm_rect64_min_t64 &&
             (long)((M + 63) / 64) * (N / 128) <= kNumCU)
-            return (g_gemm_ring8 && g_gemm_rect64_w8) ? launch_gemm_ring_rect_epi<64, 128, 2, 4>(A, W, bias, C, M, N, K, epi, st)
-                                                                        : launch_gemm_ring_rect_epi<64, 128>(A, W, bias, C, M, N, K, epi, st);
+            return launch_gemm_ring_rect_epi<64, 128>(A, W, bias, C, M, N, K, epi, st);
         // at most one 64x64 tile per CU: the deep-K ring (96 KiB, one workgroup per CU anyway) -- one frame's fc2 24.5 -> 21.9 us,
         // its out-proj 8.6 -> 8.0 (cold weights, tools/deepk_probe.py); with more tiles than CUs two plain-ring workgroups per CU win
         if (g_gemm_deepk && !tail && epi <= HMM_EPI_F32 && (K >> 6) % 2 == 0 && K >= 1024 && (long)((M + 63) / 64) * (N / 64) <= kNumCU)

@@ -1,15 +1,92 @@
 """Audit of the few-row GEMM dispatcher: for every GEMM of a vision block at 2 ... 12 frames' rows (and audio at 2 ... 8 segments, text at
 10 ... 40 questions) the dispatcher's choice against every named tile geometry, alone with COLD weights; prints the shapes where some
 geometry beats the choice by more than 5 %.  Candidates only: a rule is kept after an A/B in the forwards (tools/knob_ab_probe.py).
-usage: dispatch_audit_probe.py [out.json] [vision|audio|text] [few]"""
+usage: dispatch_audit_probe.py [out.json] [vision|audio|text] [few]
+
+       dispatch_audit_probe.py --check [out.json]
+The dispatcher is FROZEN (round 6).  --check reads the rules table out of the probe build (kDispatchRules in gemm_bf16.hip:
+knob, shipped limit, off value, the forwards it fires on) and re-times every rule on its own forwards: wall clock per forward
+with the rule at its limit and switched off, interleaved in three rounds in ONE process, embeddings compared bit for bit.  A rule
+whose best gain is below 2 % on this run is to be deleted from the table (not re-tuned)."""
 import json
 import sys
+import time
 
 import torch
 
-from probe_common import load_probe, event_ms
+from probe_common import load_probe, event_ms, setter
 
 L, lib = load_probe()
+
+
+def check(out_path):
+    import ctypes as C
+    from hippomm_amd.encoder import HipTower, synthetic_state_dict
+    lib.hmm_probe_dispatch_rules.restype = C.c_char_p
+    rules = json.loads(lib.hmm_probe_dispatch_rules().decode())
+    by_tower = {}
+    for r in rules:
+        for part in r["forwards"].split(";"):
+            tower, batches = part.split(":")
+            for b in batches.split(","):
+                by_tower.setdefault(tower, []).append((r, int(b)))
+
+    def wall_ms(fn, iters):
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / iters * 1e3
+
+    rows = []
+    for kind, items in by_tower.items():
+        tower = HipTower(kind, synthetic_state_dict((kind,), seed=99))
+        for r, B in items:
+            if kind == "text":
+                x = torch.randint(1, 49000, (B, 77), device="cuda")
+                x[:, 0], x[:, 20] = 49406, 49407
+            elif kind == "audio":
+                x = torch.randn(B, 3, 1, 128, 204, device="cuda")
+            else:
+                x = torch.randn(B, 3, 224, 224, device="cuda")
+            out = torch.empty(B, 1024, device="cuda")
+            set_knob = setter(lib, r["knob"])
+            iters = 40 if B <= 32 else 8
+            ms, outs = {"on": [], "off": []}, {}
+            for _ in range(3):
+                for tag, v in (("on", r["limit"]), ("off", r["off"])):
+                    set_knob(v)
+                    ms[tag].append(wall_ms(lambda: tower.forward_into(x, out), iters))
+                    outs[tag] = out.clone()
+            set_knob(r["limit"])
+            on, off = min(ms["on"]), min(ms["off"])
+            rows.append({"knob": r["knob"], "limit": r["limit"], "off": r["off"], "tower": kind, "batch": B, "ms_on": round(on, 4),
+                         "ms_off": round(off, 4), "gain_pct": round((off - on) / off * 100, 2),
+                         "same_bits": bool(torch.equal(outs["on"], outs["off"]))})
+            print(json.dumps(rows[-1]), flush=True)
+        del tower
+        torch.cuda.empty_cache()
+    verdict = []
+    for r in rules:
+        mine = [x for x in rows if x["knob"] == r["knob"]]
+        best = max(x["gain_pct"] for x in mine)
+        verdict.append({"knob": r["knob"], "limit": r["limit"], "what": r["what"], "evidence": r["evidence"], "best_gain_pct": best,
+                        "worst_gain_pct": min(x["gain_pct"] for x in mine), "keep": best >= 2.0,
+                        "bits_equal_everywhere": all(x["same_bits"] for x in mine)})
+        print(json.dumps(verdict[-1]), flush=True)
+    doc = {"what": "every rule of the frozen few-row dispatcher (kDispatchRules) on / off on its own forwards, interleaved, one process; "
+                   "gain_pct = (off - on) / off; keep = best gain >= 2 % on this box", "rules": verdict, "forwards": rows}
+    if out_path:
+        json.dump(doc, open(out_path, "w"), indent=1)
+
+
+if "--check" in sys.argv:
+    check(next((a for a in sys.argv[1:] if not a.startswith("--")), None))
+    sys.exit(0)
+
 EPI = {"bias": 0, "gelu": 1, "resid": 2}
 TILES = {"auto": -1, "auto_tiled": -2, "sliver": 5, "ring32": 8, "ring32_k2": 9, "ring32_k4": 10, "db128": 0, "pp": 3, "ring128": 6, "ring64": 7, "ring64_k2": 11, "r128x64": 12, "r64x128": 13, "r128x128w8": 14, "r128x64w8": 15}
 st = L.stream_ptr()
