@@ -137,15 +137,12 @@ __global__ __launch_bounds__(1024) void topk_chunk_kernel(const void* __restrict
 // but k keys per block (8*k B) is written, and the follow-up passes see blocks*k keys instead of N.
 constexpr int kFusedK = 128;
 
-// run_if (may be null): the kernel returns at once when *run_if == 0 -- the exact scan as the conditional fallback of the
-// bf16-prefilter path (cosine_topk_prefilter.hip).
+// The streaming body: every wave appends the order keys of its rows to the block's LDS list `cand` (kFusedCap entries), which is cut
+// back to its best k whenever it could overflow and once at the end; the block's best k keys, sorted, go to out[blockIdx.x * k ..].
 template <bool NT>
-__global__ __launch_bounds__(256) void scan_topk_kernel(const float4* __restrict__ store, int64_t n_rows,
-                                                        const float4* __restrict__ query, int k,
-                                                        uint64_t* __restrict__ out, const int* __restrict__ run_if) {
-    __shared__ uint64_t cand[kFusedCap];
-    __shared__ int count;
-    if (run_if != nullptr && *run_if == 0) return;             // workgroup-uniform
+__device__ __forceinline__ void scan_topk_body(const float4* __restrict__ store, int64_t n_rows, const float4* __restrict__ query, int k,
+                                               uint64_t* __restrict__ out, uint64_t* cand, int* count_p) {
+    int& count = *count_p;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -205,6 +202,71 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const float4* __restrict
     for (int t = threadIdx.x; t < k; t += 256) out[(int64_t)blockIdx.x * k + t] = t < n ? cand[t] : 0ull;
 }
 
+template <bool NT>
+__global__ __launch_bounds__(256) void scan_topk_kernel(const float4* __restrict__ store, int64_t n_rows,
+                                                        const float4* __restrict__ query, int k,
+                                                        uint64_t* __restrict__ out) {
+    __shared__ uint64_t cand[kFusedCap];
+    __shared__ int count;
+    scan_topk_body<NT>(store, n_rows, query, k, out, cand, &count);
+}
+
+// Best 64 of n_keys keys produced by key_at(i), through a 1024-key LDS window (the best 64 so far stay at w[0..63], 960 new keys per
+// round): for the exact scan's conditional fallback below, which must not cost the streaming kernel its occupancy.
+template <class F>
+__device__ __forceinline__ void top64_of_stream(uint64_t* w, int n_keys, F key_at) {
+    int base = 0, keep = 0;
+    do {
+        const int take = kFusedCap - keep;
+        for (int t = threadIdx.x; t < take; t += blockDim.x) w[keep + t] = base + t < n_keys ? key_at(base + t) : 0ull;
+        base += take;
+        keep = 64;
+        __syncthreads();
+        top64_desc(w, kFusedCap);                                            // ends on a barrier: w[0..63] = the best so far
+    } while (base < n_keys);
+}
+
+// The exact scan as the CONDITIONAL FALLBACK of the bf16-prefilter path (cosine_topk_prefilter.hip), one launch with its own symbol:
+// returns at once unless *run_if != 0 (the usual case: 2048 workgroups that exit, ~4 us); otherwise scan_topk_kernel's streaming body,
+// and the workgroup that takes the last ticket (device-scope counter, zeroed by prefilter_final_kernel) finishes as topk_final_kernel
+// does -- the k lists with the largest maxima hold the answer -- in the 8 KB of LDS the streaming body already has.  k <= 64.
+__global__ __launch_bounds__(256) void exact_scan_fallback_kernel(const float4* __restrict__ store, int64_t n_rows,
+                                                                  const float4* __restrict__ query, int k,
+                                                                  uint64_t* __restrict__ lists, const int* __restrict__ run_if,
+                                                                  unsigned* __restrict__ ticket, int64_t* __restrict__ idx_out,
+                                                                  float* __restrict__ sim_out, int32_t* __restrict__ n_out) {
+    __shared__ uint64_t cand[kFusedCap];
+    __shared__ uint64_t winners[64];
+    __shared__ int count;
+    __shared__ int last;
+    if (*run_if == 0) return;                                               // workgroup-uniform
+    scan_topk_body<true>(store, n_rows, query, k, lists, cand, &count);
+    __threadfence();                                                        // this block's list is visible device-wide ...
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;    // ... before its ticket is
+    __syncthreads();
+    if (!last) return;
+    __threadfence();                                                        // every other block's list is visible here
+    const int n_blocks = (int)gridDim.x;
+    const int64_t n_waves = (int64_t)n_blocks * 4;
+    const volatile uint64_t* all = lists;
+    top64_of_stream(cand, n_blocks, [&](int b) { return all[(int64_t)b * k]; });          // the block maxima
+    if (threadIdx.x < 64) winners[threadIdx.x] = cand[threadIdx.x];
+    __syncthreads();
+    const int n_win = n_blocks < k ? n_blocks : k;
+    top64_of_stream(cand, n_win * k, [&](int t) {
+        const uint64_t top = winners[t / k];
+        if (top == 0ull) return (uint64_t)0;
+        const int blk = (int)((((int64_t)(top & 0xFFFFFFFFull) >> 1) % n_waves) >> 2);     // row r belongs to wave (r / 2) % n_waves
+        return (uint64_t)all[(int64_t)blk * k + (t % k)];
+    });
+    if (threadIdx.x == 0) { *n_out = k; *ticket = 0u; }
+    for (int t = threadIdx.x; t < k; t += 256) {
+        idx_out[t] = (int64_t)(cand[t] & 0xFFFFFFFFull);
+        sim_out[t] = order_bits_inverse((uint32_t)(cand[t] >> 32));
+    }
+}
+
 // Final selection for the fused path when k*k <= kChunk.  Every scan block left its best k keys, sorted,
 // at cand[b*k ..].  The global top-k can only contain keys of the k blocks with the largest maxima: a key
 // below the k-th largest block maximum has k better keys (those maxima) ahead of it.  One workgroup sorts
@@ -214,9 +276,8 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const float4* __restrict
 __global__ __launch_bounds__(1024) void topk_final_kernel(const uint64_t* __restrict__ cand, int n_blocks, int k,
                                                           int64_t n_waves, uint64_t* __restrict__ keys_out, int k_pad,
                                                           int64_t* __restrict__ idx_out, float* __restrict__ sim_out,
-                                                          int32_t* __restrict__ n_out, const int* __restrict__ run_if) {
+                                                          int32_t* __restrict__ n_out) {
     __shared__ uint64_t mx[kScanBlocks];       // block maxima
-    if (run_if != nullptr && *run_if == 0) return;
     __shared__ uint64_t s[kChunk];             // keys of the winning blocks
     const int tid = threadIdx.x;
     const int n2 = pow2_at_least(n_blocks, 64);
@@ -406,7 +467,7 @@ struct ScanOut {                 // where the result of run_scan lives
 
 // Runs scan + selection up to (not including) the final decode / key copy.
 static int run_scan(const float* store, int64_t n, int dim, const float* query, int k,
-                    void* ws, size_t ws_bytes, hipStream_t st, ScanOut* out, const int* run_if = nullptr) {
+                    void* ws, size_t ws_bytes, hipStream_t st, ScanOut* out) {
     const uint64_t** best = &out->best;
     int* k_eff = &out->k_eff;
     out->fused = false;
@@ -431,14 +492,13 @@ static int run_scan(const float* store, int64_t n, int dim, const float* query, 
     if (!p.full_sort && n > kChunk && p.k_eff <= kFusedK) {
         // fused: the streaming kernel emits k candidates per block; reduce blocks*k keys by chunk sorts
         scan_topk_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n,
-                                                       reinterpret_cast<const float4*>(query), p.k_eff, buf_a, run_if);
+                                                       reinterpret_cast<const float4*>(query), p.k_eff, buf_a);
         HMM_LAUNCH_CHECK();
         if ((int64_t)p.k_eff * p.k_eff <= kChunk && blocks <= kScanBlocks) {     // one-kernel finish
             out->fused = true; out->cand = buf_a; out->n_blocks = blocks; out->n_waves = (int64_t)blocks * 4;
             out->best = nullptr;
             return HMM_OK;
         }
-        HMM_REQUIRE(run_if == nullptr, HMM_E_INVALID, "cosine_topk: the conditional scan needs k * k <= %d", kChunk);
         int64_t count = (int64_t)blocks * p.k_eff;
         uint64_t* cur = buf_a;
         uint64_t* nxt = buf_b;
@@ -454,7 +514,6 @@ static int run_scan(const float* store, int64_t n, int dim, const float* query, 
         return HMM_OK;
     }
 
-    HMM_REQUIRE(run_if == nullptr, HMM_E_INVALID, "cosine_topk: the conditional scan needs n > %d and k <= %d", kChunk, kFusedK);
     scan_sims_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n,
                                                    reinterpret_cast<const float4*>(query), sims);
     HMM_LAUNCH_CHECK();
@@ -488,14 +547,20 @@ static int run_scan(const float* store, int64_t n, int dim, const float* query, 
     return HMM_OK;
 }
 
-// hmm_cosine_topk executed only when *run_if != 0 on the device (both kernels return at once otherwise); n > 4096 and k <= 64.
-int cosine_topk_if(const int* run_if, const float* store, int64_t n, const float* query, int k, int64_t* idx_out, float* sim_out,
-                   int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t st) {
-    ScanOut r{};
-    int rc = run_scan(store, n, HMM_FEATURE_DIM, query, k, ws, ws_bytes, st, &r, run_if);
-    if (rc != HMM_OK) return rc;
-    HMM_REQUIRE(r.fused, HMM_E_INVALID, "cosine_topk_if: not the fused path");
-    topk_final_kernel<<<1, 1024, 0, st>>>(r.cand, r.n_blocks, r.k_eff, r.n_waves, nullptr, 0, idx_out, sim_out, n_out, run_if);
+// hmm_cosine_topk executed only when *run_if != 0 on the device, as ONE conditional launch (exact_scan_fallback_kernel); n > 4096 rows
+// and k <= 64.  `ticket` must read 0 when the kernel starts (prefilter_final_kernel zeroes it).  ws: hmm_cosine_topk's workspace.
+int cosine_topk_if(const int* run_if, unsigned* ticket, const float* store, int64_t n, const float* query, int k, int64_t* idx_out,
+                   float* sim_out, int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t st) {
+    HMM_REQUIRE(run_if && ticket && n > kChunk && n < (int64_t)0xFFFFFFFFll && k >= 1 && k <= 64 && k <= n, HMM_E_INVALID,
+                "cosine_topk_if: needs more than %d rows and k <= 64", kChunk);
+    const ScanPlan p = make_plan(n, k);
+    HMM_REQUIRE(ws_bytes >= p.total, HMM_E_WORKSPACE, "cosine_topk_if: workspace %zu < required %zu", ws_bytes, p.total);
+    int64_t waves_needed = (n + 1) / 2;
+    int blocks = (int)((waves_needed + 3) / 4);
+    if (blocks > kScanBlocks) blocks = kScanBlocks;
+    exact_scan_fallback_kernel<<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n, reinterpret_cast<const float4*>(query),
+                                                       k, reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + p.off_a), run_if, ticket,
+                                                       idx_out, sim_out, n_out);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
@@ -519,7 +584,7 @@ extern "C" int hmm_cosine_topk(const float* store_dev, int64_t n_rows, int dim, 
     if (rc != HMM_OK) return rc;
     if (r.fused) {
         topk_final_kernel<<<1, 1024, 0, st>>>(r.cand, r.n_blocks, r.k_eff, r.n_waves, nullptr, 0, idx_out_dev, sim_out_dev,
-                                              n_out_dev, nullptr);
+                                              n_out_dev);
     } else {
         decode_kernel<<<(r.k_eff + 255) / 256, 256, 0, st>>>(r.best, r.k_eff, idx_out_dev, sim_out_dev, n_out_dev);
     }
@@ -537,7 +602,7 @@ extern "C" int hmm_cosine_topk_keys(const float* store_dev, int64_t n_rows, int 
     if (rc != HMM_OK) return rc;
     if (r.fused) {
         topk_final_kernel<<<1, 1024, 0, st>>>(r.cand, r.n_blocks, r.k_eff, r.n_waves, keys_out_dev, k, nullptr, nullptr,
-                                              nullptr, nullptr);
+                                              nullptr);
     } else {
         copy_keys_kernel<<<(k + 255) / 256, 256, 0, st>>>(r.best, r.k_eff, keys_out_dev, k);
     }
@@ -579,7 +644,7 @@ extern "C" int hmm_op_scan_topk_only(const float* store_dev, int64_t n_rows, con
     int blocks = (int)((waves_needed + 3) / 4);
     if (blocks > kScanBlocks) blocks = kScanBlocks;
     scan_topk_kernel<true><<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
-        reinterpret_cast<const float4*>(store_dev), n_rows, reinterpret_cast<const float4*>(query_dev), k, cand_dev, nullptr);
+        reinterpret_cast<const float4*>(store_dev), n_rows, reinterpret_cast<const float4*>(query_dev), k, cand_dev);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }

@@ -78,7 +78,7 @@ __device__ __forceinline__ float dot8_bf16(const uint4& x, const float4& qa, con
 // row per wave, streams 12 % slower -- four distant pieces per block and iteration instead of one run -- for no fewer fallbacks.)
 __global__ __launch_bounds__(256) void prefilter_topk_kernel(const uint4* __restrict__ shadow, int64_t n_rows,
                                                              const float4* __restrict__ query, int k,
-                                                             uint64_t* __restrict__ out) {
+                                                             uint64_t* __restrict__ out, uint64_t* __restrict__ maxima) {
     __shared__ uint64_t cand[kFusedCap];
     __shared__ int count;
     const int lane = threadIdx.x & 63;
@@ -141,23 +141,40 @@ __global__ __launch_bounds__(256) void prefilter_topk_kernel(const uint4* __rest
     }
     const int n = count;
     for (int t = threadIdx.x; t < k; t += 256) out[(int64_t)blockIdx.x * k + t] = t < n ? cand[t] : 0ull;
+    if (threadIdx.x == 0) maxima[blockIdx.x] = n > 0 ? cand[0] : 0ull;       // the block maxima once more, contiguous: pass 2's first read
 }
+
+// Probe build only: thread 0 of pass 2 stamps the 100-MHz wall clock after each phase (tools/prefilter_final_stamps_probe.py).
+#ifdef HMM_PROBE
+static long long* g_pf_stamps = nullptr;
+extern "C" void hmm_probe_set_prefilter_stamps(long long* stamps_dev) { g_pf_stamps = stamps_dev; }
+#define HMM_PF_STAMP_PARAM , long long* __restrict__ stamps
+#define HMM_PF_STAMP_ARG , g_pf_stamps
+#define HMM_PF_STAMP(i) do { if (stamps != nullptr && threadIdx.x == 0) stamps[i] = wall_clock64(); } while (0)
+#else
+#define HMM_PF_STAMP_PARAM
+#define HMM_PF_STAMP_ARG
+#define HMM_PF_STAMP(i)
+#endif
 
 // ---- pass 2: threshold, candidates, exact re-score, answer (or the fallback flag) -------------------------------------------
 // lists: n_blocks x kk keys (kk >= k entries per block, sorted descending, 0-padded).
-__global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* __restrict__ lists, int n_blocks, int k, int kk,
+__global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* __restrict__ lists, const uint64_t* __restrict__ maxima,
+                                                               unsigned* __restrict__ fallback_ticket, int n_blocks, int k, int kk,
                                                                int64_t n_waves, const float4* __restrict__ store,
                                                                const float4* __restrict__ query,
                                                                int64_t* __restrict__ idx_out, float* __restrict__ sim_out,
                                                                int32_t* __restrict__ n_out, int* __restrict__ fallback,
-                                                               int* __restrict__ stats /* [2]: candidates, saturated lists */) {
+                                                               int* __restrict__ stats /* [2]: candidates, saturated lists */
+                                                               HMM_PF_STAMP_PARAM) {
     __shared__ uint64_t mx[kScanBlocks];
     __shared__ uint64_t s[kChunk];
     __shared__ uint32_t cand_row[kPrefilterCap];
     __shared__ uint16_t hot[kScanBlocks];
     __shared__ int n_cand, n_sat, n_hot;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { n_cand = 0; n_sat = 0; n_hot = 0; }
+    HMM_PF_STAMP(0);
+    if (tid == 0) { n_cand = 0; n_sat = 0; n_hot = 0; *fallback_ticket = 0u; }          // the ticket of the conditional exact scan behind this kernel
     // the k-th largest approximate key: the k lists with the largest maxima hold the k largest keys (every list keeps kk >= k
     // entries).  (The k-th largest block MAXIMUM is a cheaper lower bound -- two dependent round trips fewer -- but when the k best
     // rows sit in fewer than k blocks, as the frames of one scene do, it falls to the background level and thousands of rows
@@ -167,11 +184,13 @@ __global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* _
 #pragma unroll
     for (int i = 0; i < kScanBlocks / 1024; ++i) {
         const int t = tid + i * 1024;
-        own[i] = t < n_blocks ? lists[(int64_t)t * kk] : 0ull;
+        own[i] = t < n_blocks ? maxima[t] : 0ull;
         if (t < n2) mx[t] = own[i];
     }
     __syncthreads();
+    HMM_PF_STAMP(1);                                                          // maxima loaded
     top64_desc(mx, n2);
+    HMM_PF_STAMP(2);                                                          // ... ranked
     const int n_win = n_blocks < k ? n_blocks : k;
     const int m2 = pow2_at_least(n_win * kk, 64);
     for (int t = tid; t < m2; t += 1024) {
@@ -187,7 +206,9 @@ __global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* _
         s[t] = key;
     }
     __syncthreads();
+    HMM_PF_STAMP(3);                                                          // winners' lists gathered
     top64_desc(s, m2);
+    HMM_PF_STAMP(4);                                                          // ... ranked: the k-th largest approximate key
     const uint64_t kth = s[k - 1];                                            // 0 = fewer than k rows in all (launcher excludes it)
     const float t_lo = order_bits_inverse((uint32_t)(kth >> 32)) - 2.0f * kPrefilterEps;
     const uint32_t thr = order_bits(t_lo);                                    // NaN k-th -> 0xFFFFFFFF: only NaN rows pass
@@ -198,22 +219,34 @@ __global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* _
         if (own[i] != 0ull && (uint32_t)(own[i] >> 32) >= thr) hot[atomicAdd(&n_hot, 1)] = (uint16_t)(tid + i * 1024);
     __syncthreads();
     // one wave per hot list, one entry per lane: every entry at or above the threshold is a candidate; a list whose LAST entry
-    // passes may have dropped some (saturated)
-    for (int h = wave; h < n_hot; h += 16) {
-        const int b = hot[h];
-        const uint64_t key = lane < kk ? lists[(int64_t)b * kk + lane] : 0ull;
-        const bool pass = key != 0ull && (uint32_t)(key >> 32) >= thr;
-        const unsigned long long mask = __ballot(pass);
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&n_cand, __popcll(mask));
-        base = __shfl(base, 0, 64);
-        if (pass) {
-            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-            if (pos < kPrefilterCap) cand_row[pos] = (uint32_t)(key & 0xFFFFFFFFull);
-            if (lane == kk - 1) atomicAdd(&n_sat, 1);
+    // passes may have dropped some (saturated).  A wave loads its lists of a round (up to 8) before it looks at any of them: one
+    // memory latency per 128 hot lists instead of one per 16.
+    constexpr int kHotUnroll = 8;
+    for (int h0 = wave; h0 < n_hot; h0 += 16 * kHotUnroll) {
+        uint64_t keys[kHotUnroll];
+#pragma unroll
+        for (int u = 0; u < kHotUnroll; ++u) {
+            const int h = h0 + 16 * u;
+            keys[u] = (h < n_hot && lane < kk) ? lists[(int64_t)hot[h] * kk + lane] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < kHotUnroll; ++u) {
+            if (h0 + 16 * u >= n_hot) break;                                  // wave-uniform
+            const uint64_t key = keys[u];
+            const bool pass = key != 0ull && (uint32_t)(key >> 32) >= thr;
+            const unsigned long long mask = __ballot(pass);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&n_cand, __popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (pass) {
+                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < kPrefilterCap) cand_row[pos] = (uint32_t)(key & 0xFFFFFFFFull);
+                if (lane == kk - 1) atomicAdd(&n_sat, 1);
+            }
         }
     }
     __syncthreads();
+    HMM_PF_STAMP(5);                                                          // hot lists read, candidates listed
     const int m = n_cand;
     const bool fall = kth == 0ull || n_sat > 0 || m > kPrefilterCap;
     if (tid == 0) {
@@ -251,7 +284,9 @@ __global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* _
         }
     }
     __syncthreads();
+    HMM_PF_STAMP(6);                                                          // candidates re-scored
     top64_desc(s, m_pad);
+    HMM_PF_STAMP(7);
     if (tid == 0 && n_out) *n_out = k;
     for (int t = tid; t < k; t += 1024) {
         idx_out[t] = (int64_t)(s[t] & 0xFFFFFFFFull);
@@ -401,7 +436,7 @@ __global__ __launch_bounds__(1024) void segment_prefilter_kernel(const float* __
     }
 }
 
-struct PrefilterPlan { size_t off_exact, off_lists, off_flag, total; int blocks; };
+struct PrefilterPlan { size_t off_exact, off_lists, off_maxima, off_flag, total; int blocks; };
 
 static PrefilterPlan prefilter_plan(int64_t n, int k) {
     PrefilterPlan p{};
@@ -411,7 +446,8 @@ static PrefilterPlan prefilter_plan(int64_t n, int k) {
     int64_t waves_needed = (n + 3) / 4;
     int blocks = (int)((waves_needed + 3) / 4);
     p.blocks = blocks > kScanBlocks ? kScanBlocks : blocks;
-    p.off_flag = p.off_lists + align_up((size_t)kScanBlocks * (size_t)kPrefilterMaxK * 8, 256);
+    p.off_maxima = p.off_lists + align_up((size_t)kScanBlocks * (size_t)kPrefilterMaxK * 8, 256);
+    p.off_flag = p.off_maxima + align_up((size_t)kScanBlocks * 8, 256);          // int flag, then the fallback's unsigned ticket
     p.total = p.off_flag + 256;
     return p;
 }
@@ -471,15 +507,17 @@ extern "C" int hmm_cosine_topk_prefilter(const float* store_dev, const void* sha
     uint64_t* lists = reinterpret_cast<uint64_t*>(ws + p.off_lists);
     int* flag = reinterpret_cast<int*>(ws + p.off_flag);
     const int kk = prefilter_list_len(k);
+    uint64_t* maxima = reinterpret_cast<uint64_t*>(ws + p.off_maxima);
+    unsigned* ticket = reinterpret_cast<unsigned*>(flag + 1);
     prefilter_topk_kernel<<<p.blocks, 256, 0, st>>>(static_cast<const uint4*>(shadow_dev), n_rows,
-                                                    reinterpret_cast<const float4*>(query_dev), kk, lists);
+                                                    reinterpret_cast<const float4*>(query_dev), kk, lists, maxima);
     HMM_LAUNCH_CHECK();
-    prefilter_final_kernel<<<1, 1024, 0, st>>>(lists, p.blocks, k, kk, (int64_t)p.blocks * 4, reinterpret_cast<const float4*>(store_dev),
-                                               reinterpret_cast<const float4*>(query_dev), idx_out_dev, sim_out_dev, n_out_dev, flag,
-                                               stats_out_dev);
+    prefilter_final_kernel<<<1, 1024, 0, st>>>(lists, maxima, ticket, p.blocks, k, kk, (int64_t)p.blocks * 4,
+                                               reinterpret_cast<const float4*>(store_dev), reinterpret_cast<const float4*>(query_dev),
+                                               idx_out_dev, sim_out_dev, n_out_dev, flag, stats_out_dev HMM_PF_STAMP_ARG);
     HMM_LAUNCH_CHECK();
-    // the exact scan, executed only when the flag is up (both kernels return at once otherwise)
-    return cosine_topk_if(flag, store_dev, n_rows, query_dev, k, idx_out_dev, sim_out_dev, n_out_dev, ws + p.off_exact, p.off_lists, st);
+    // the exact scan, ONE conditional launch executed only when the flag is up (its workgroups return at once otherwise)
+    return cosine_topk_if(flag, ticket, store_dev, n_rows, query_dev, k, idx_out_dev, sim_out_dev, n_out_dev, ws + p.off_exact, p.off_lists, st);
 }
 
 extern "C" size_t hmm_cosine_topk_segmented_prefilter_workspace_bytes(int64_t n_rows, int n_segments, int k) {

@@ -72,7 +72,7 @@ __device__ __forceinline__ void exact_row_sim4(const float4* const (&row_lane)[4
     }
 }
 
-int cosine_topk_if(const int* run_if, const float* store, int64_t n, const float* query, int k, int64_t* idx_out, float* sim_out,
-                   int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t st);
+int cosine_topk_if(const int* run_if, unsigned* ticket, const float* store, int64_t n, const float* query, int k, int64_t* idx_out,
+                   float* sim_out, int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace hmm

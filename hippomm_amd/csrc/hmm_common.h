@@ -71,7 +71,33 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-// ---- wave reductions (64 lanes) ----------------------------------------------------------
+// ---- lane exchanges and wave reductions (64 lanes) ---------------------------------------------
+// The 32-bit value of lane (lane ^ J) without the LDS crossbar: XOR 1 / 2 are quad permutations and XOR 8 a rotation of the 16-lane
+// row (data-parallel-primitive modifiers on a v_mov), XOR 4 two bank-masked row shifts, XOR 16 / 32 gfx950's v_permlane16_swap /
+// v_permlane32_swap.  ~10 cycles where ds_bpermute answers in ~120 -- and every step of a bitonic network waits for the previous one
+// (topk_tournament.h).
+__device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+template <int J>
+__device__ __forceinline__ int lane_xor_b32(int v) {
+    if constexpr (J == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);            // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+    else if constexpr (J == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, true);                      // row_shl:4 -> banks 0, 2 (lane + 4)
+        return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);                             // row_shr:4 -> banks 1, 3 (lane - 4)
+    } else if constexpr (J == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);    // row_ror:8
+    else if constexpr (J == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);     // odd rows of [0] <-> even rows of [1]
+        return (int)((lane_id() & 16u) ? r[0] : r[1]);
+    } else {
+        static_assert(J == 32, "lane_xor_b32: J must be a power of two below 64");
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);     // upper half of [0] <-> lower half of [1]
+        return (int)((lane_id() & 32u) ? r[0] : r[1]);
+    }
+}
+
+// Butterfly reductions stay on __shfl_xor (ds_bpermute): in the streaming kernels they run beside a saturated VALU, and the LDS
+// crossbar is the idle unit there -- with the VALU exchanges above the bf16 prefilter pass slowed from 304 to 314 us
+// (profiles/r6_scan_trace_summary_valu_wave_sum.json); the same arithmetic and bits either way.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -19,28 +19,41 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// The key of lane (lane ^ J), through the crossbar-free exchanges of hmm_common.h (lane_xor_b32).  A compare-exchange step is a chain
+// link: the next one needs its result, and a selection kernel is nothing but such chains (a best-64 tournament over 2048 keys = 72
+// dependent steps); with ds_bpermute (~120 cycles a step) prefilter_final_kernel's two rankings took 7.3 us each, 4.7 with the row
+// exchanges alone (profiles/r6_prefilter_final_stamps*.json).
+template <int J>
+__device__ __forceinline__ uint64_t lane_xor(uint64_t v, int) {
+    const uint32_t lo = (uint32_t)lane_xor_b32<J>((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)lane_xor_b32<J>((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// One compare-exchange of the bitonic network: stage K (runs of K lanes, descending in even runs), distance J.
+template <int K, int J>
+__device__ __forceinline__ void bitonic_steps(uint64_t& v, int lane) {
+    const uint64_t o = lane_xor<J>(v, lane);
+    const bool desc = K >= 64 || (lane & K) == 0;
+    const bool keep_max = ((lane & J) == 0) == desc;
+    v = ((v > o) == keep_max) ? v : o;
+    if constexpr (J > 1) bitonic_steps<K, J / 2>(v, lane);
+}
+template <int K>
+__device__ __forceinline__ void bitonic_stages(uint64_t& v, int lane) {
+    bitonic_steps<K, K / 2>(v, lane);
+    if constexpr (K < 64) bitonic_stages<K * 2>(v, lane);
+}
+
 // v: one key per lane, bitonic across the wave -> sorted descending by lane
 __device__ __forceinline__ uint64_t wave_bitonic_merge_desc(uint64_t v, int lane) {
-#pragma unroll
-    for (int j = 32; j > 0; j >>= 1) {
-        const uint64_t o = shfl_xor_u64(v, j);
-        const bool keep_max = (lane & j) == 0;
-        v = ((v > o) == keep_max) ? v : o;
-    }
+    bitonic_steps<64, 32>(v, lane);
     return v;
 }
 
 // v: one key per lane, any order -> sorted descending by lane
 __device__ __forceinline__ uint64_t wave_sort_desc(uint64_t v, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1)
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint64_t o = shfl_xor_u64(v, j);
-            const bool desc = (lane & k) == 0;                 // k = 64: every lane
-            const bool keep_max = ((lane & j) == 0) == desc;
-            v = ((v > o) == keep_max) ? v : o;
-        }
+    bitonic_stages<2>(v, lane);
     return v;
 }
 
@@ -49,7 +62,14 @@ __device__ __forceinline__ uint64_t wave_sort_desc(uint64_t v, int lane) {
 __device__ __forceinline__ void top64_desc(uint64_t* s, int n2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     int chunks = n2 >> 6;
-    for (int c = wave; c < chunks; c += n_waves) s[c * 64 + lane] = wave_sort_desc(s[c * 64 + lane], lane);
+    for (int c = wave; c < chunks; c += 2 * n_waves) {         // two chunks per wave at a time: two independent chains interleave
+        const int c1 = c + n_waves;
+        uint64_t v0 = s[c * 64 + lane], v1 = c1 < chunks ? s[c1 * 64 + lane] : 0ull;
+        bitonic_stages<2>(v0, lane);
+        bitonic_stages<2>(v1, lane);
+        s[c * 64 + lane] = v0;
+        if (c1 < chunks) s[c1 * 64 + lane] = v1;
+    }
     while (chunks > 1) {
         const int pairs = chunks >> 1;
         __syncthreads();                                       // the chunks of this level are complete

@@ -23,11 +23,14 @@ def main():
     ks = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]) / 1e3, int(r["End_Timestamp"]) / 1e3,
            int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))) for r in rows]
     out = {}
-    for tag, first, members in (("exact", "scan_topk_kernel", ("scan_topk_kernel", "topk_final_kernel")),
-                                ("prefilter", "prefilter_topk_kernel", None), ("multi16", "scan_multi_kernel", None)):
+    for tag, first in (("exact", "scan_topk_kernel"), ("prefilter", "prefilter_topk_kernel"), ("multi16", "scan_multi_kernel"),
+                       ("scan_kernel_only", "scan_topk_kernel")):
         starts = [i for i, k in enumerate(ks) if k[0].startswith(first) and k[3] > 64 and k[2] - k[1] > 50]
-        if tag == "exact":                                      # the exact scan also runs (skipped) inside prefilter queries: keep the
-            starts = [i for i in starts if ks[i][2] - ks[i][1] > 100 and (i == 0 or not ks[i - 1][0].startswith("prefilter"))]
+        if tag == "exact":                                      # streaming launches that ARE followed by the finishing kernel
+            starts = [i for i in starts if i + 1 < len(ks) and ks[i + 1][0].startswith("topk_final_kernel")]
+        if tag == "scan_kernel_only":                           # ... and those followed by another streaming launch
+            starts = [i for i in starts if i + 1 < len(ks) and ks[i + 1][0].startswith("scan_topk_kernel")
+                      and (i == 0 or ks[i - 1][0].startswith("scan_topk_kernel"))]
         if len(starts) < 52:
             continue
         starts = starts[-51:]

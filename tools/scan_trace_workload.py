@@ -1,6 +1,5 @@
 """Workload for `rocprofv3 --kernel-trace`: back-to-back feature_search queries on a resident 1M x 1024 store -- 60 through
-hmm_cosine_topk, 60 through hmm_cosine_topk_prefilter, 60 through the 16-query pass -- each group after its own warm-up, with a
-marker launch (torch.zeros fill) between groups.  Also prints the HIP-event time per query of every group (under the tracer).
+hmm_cosine_topk, 60 through hmm_cosine_topk_prefilter, 60 through the 16-query pass -- and 60 launches of the exact scan's streaming kernel alone -- each group after its own warm-up.  Also prints the HIP-event time per query of every group (under the tracer).
     rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 tools/scan_trace_workload.py"""
 import json
 import os
@@ -9,6 +8,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+from hippomm_amd import _lib as L
 from hippomm_amd.vector_ops import FeatureStore
 
 N, K = 1_000_000, 32
@@ -22,8 +22,11 @@ q16 = torch.randn(16, 1024, generator=torch.Generator(device="cuda").manual_seed
 store = FeatureStore(rows)
 store.build_shadow()
 out = {}
+lib = L.load()
+cand = torch.empty(2048 * K, dtype=torch.int64, device="cuda")
 for tag, fn in (("exact", lambda: store.search_device(q, K)), ("prefilter", lambda: store.search_prefiltered_device(q, K)),
-                ("multi16", lambda: store.search_multi_device(q16, K))):
+                ("multi16", lambda: store.search_multi_device(q16, K)),
+                ("scan_kernel_only", lambda: L.check(lib.hmm_op_scan_topk_only(rows.data_ptr(), N, q.data_ptr(), K, cand.data_ptr(), L.stream_ptr()), "scan"))):
     for _ in range(150):
         fn()
     torch.cuda.synchronize()
