@@ -536,8 +536,11 @@ def retrieval_bench(rows, do_cpu):
         vo.disable_store_cache()
     del host_events
     out = {"what": "question -> tokenizer -> text tower (24 blocks, batch 1) -> top-5 per event over 2000 events x 500 rows "
-                   "(one pass) -> best 5 hits on the host",
-           "ms_end_to_end": round(sorted(t)[len(t) // 2] * 1e3, 3), "ms_text_tower": round(t_tower, 3),
+                   "(one pass) -> the best 5 hits of all events, ranked on the device, on the host (EventStore.top_hits: what "
+                   "INTEGRATION.md's patch for hippocampal_memory.py:3143-3153 + :3275-3277 calls); ms_end_to_end_host_ranked = the same "
+                   "with every event's hits read back and ranked in Python as the reference's loop does",
+           "ms_end_to_end": round(sorted(t2)[len(t2) // 2] * 1e3, 3),
+           "ms_end_to_end_host_ranked": round(sorted(t)[len(t) // 2] * 1e3, 3), "ms_text_tower": round(t_tower, 3),
            "ms_per_event_scan_all_events": round(t_scan, 3), "events": n_events, "rows": n_events * per_event,
            "ms_per_event_scan_bf16_prefilter": round(t_scan_pre, 3), "prefilter_identical_to_fp32_scan": pre_same,
            "unchanged_reference_loop_ms_per_event": {"numpy_store_uploaded_per_call": round(ms_upload, 4),
@@ -547,7 +550,6 @@ def retrieval_bench(rows, do_cpu):
                                                      "(xxh3, arrays <= 64 MB) before it trusts the resident copy, so an in-place "
                                                      "edit is a miss; above 64 MB only a 64 x 16 sample is compared "
                                                      "(hippomm_amd.vector_ops.enable_store_cache)"},
-           "ms_end_to_end_ranked_on_device": round(sorted(t2)[len(t2) // 2] * 1e3, 3),
            "device_ranking_equals_host_ranking": [(e, i) for e, i, _ in top2] == [(e, i) for _, e, i in top]}
     if do_cpu:
         from oracle import imagebind_oracle as ib
@@ -929,7 +931,7 @@ def encoder_parity(tower_sd, frames, emb, rows=(0, 1, 127, 128, 255)):
 
 
 def torch_rocm_reference():
-    """The same ViT-H/14 tower through stock PyTorch-ROCm operators on this GPU (tools/torch_vit_probe.py): fp32 is what the
+    """The same ViT-H/14 tower through stock PyTorch-ROCm operators on this GPU (tools/torch_vit_lib.py): fp32 is what the
     reference runs (ImageBind.forward under no_grad, no autocast, foundation_models.py:116-133), bf16 is the vendor-library
     route.  A reported reference point, never part of the product path."""
     import importlib.util

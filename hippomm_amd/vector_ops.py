@@ -157,15 +157,22 @@ class FeatureStore:
         this store.  Returns CUDA tensors idx (E,k) int64 rows within each event (-1 padded), sims (E,k) fp32,
         counts (E,) int32 = min(k, n_e).  ``prefilter``: stream the bf16 shadow (built on first use) and re-score each event's
         candidates on the fp32 rows -- the same outputs, bit for bit, for half the bytes (hmm_cosine_topk_segmented_prefilter)."""
+        return self._search_segments_packed(query, seg_offsets, k, prefilter)[1:]
+
+    def _search_segments_packed(self, query: torch.Tensor, seg_offsets: torch.Tensor, k: int, prefilter: bool = False):
+        """search_segments_device, returning (packed, idx, sims, counts): the three outputs are views of `packed`."""
         lib = _lib.load()
         dev = self.rows.device
         E = seg_offsets.numel() - 1
         need = lib.hmm_cosine_topk_segmented_workspace_bytes(len(self), E, k)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        idx = torch.empty(E, k, dtype=torch.int64, device=dev)
-        sims = torch.empty(E, k, dtype=torch.float32, device=dev)
-        counts = torch.empty(E, dtype=torch.int32, device=dev)
+        # the three outputs are views of ONE buffer (idx | sims | counts), so that a caller who wants them on the host reads them back
+        # with one copy (top_k_per_event)
+        packed = torch.empty(E * k * 12 + E * 4, dtype=torch.uint8, device=dev)
+        idx = packed[: E * k * 8].view(torch.int64).view(E, k)
+        sims = packed[E * k * 8: E * k * 12].view(torch.float32).view(E, k)
+        counts = packed[E * k * 12:].view(torch.int32)
         if prefilter and len(self) > 0:
             self.build_shadow()
             _lib.check(lib.hmm_cosine_topk_segmented_prefilter(self.rows.data_ptr(), self._shadow.data_ptr(), len(self), FEATURE_DIM,
@@ -173,12 +180,12 @@ class FeatureStore:
                                                                sims.data_ptr(), counts.data_ptr(), self._ws.data_ptr(),
                                                                self._ws.numel(), _lib.stream_ptr()),
                        "hmm_cosine_topk_segmented_prefilter")
-            return idx, sims, counts
+            return packed, idx, sims, counts
         _lib.check(lib.hmm_cosine_topk_segmented(self.rows.data_ptr(), len(self), FEATURE_DIM, query.data_ptr(),
                                                  seg_offsets.data_ptr(), E, k, idx.data_ptr(), sims.data_ptr(),
                                                  counts.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
                                                  _lib.stream_ptr()), "hmm_cosine_topk_segmented")
-        return idx, sims, counts
+        return packed, idx, sims, counts
 
     def search_multi_device(self, queries: torch.Tensor, k: int):
         """queries (Q,1024) fp32 on the store's device -> (idx (Q,k') int64, sims (Q,k') fp32) device tensors,
@@ -402,15 +409,33 @@ class EventStore(FeatureStore):
         key = torch.where(valid, torch.nan_to_num(sims, nan=float("inf")), torch.full_like(sims, float("-inf"))).reshape(-1)
         order = torch.sort(key, descending=True, stable=True).indices[: int(keep)]
         order = order[valid.reshape(-1)[order]]                 # fewer than `keep` hits in the whole store
-        ev = (order // idx.shape[1]).cpu().tolist()
-        rows = idx.reshape(-1)[order].cpu().tolist()
-        vals = sims.reshape(-1)[order].cpu().tolist()
-        return list(zip(ev, rows, vals))
+        flat_idx, flat_sims = idx.reshape(-1)[order], sims.reshape(-1)[order]
+        # ONE read-back of the `keep` hits: event, row and similarity as doubles (exact for int32-range rows and fp32 similarities)
+        hits = torch.stack([(order // idx.shape[1]).double(), flat_idx.double(), flat_sims.double()]).cpu().numpy()
+        return [(int(e), int(r), float(np.float32(v))) for e, r, v in zip(hits[0], hits[1], hits[2])]
 
     def top_k_per_event(self, query, k: int = 5, prefilter: bool = False):
         """[(indices int64[k_e], sims float32[k_e]) for every event], each exactly what
         ``top_k_cosine_similarity(query, event_features, k)`` returns for that event."""
         q = _query_to_device(query, self.rows.device)
-        idx, sims, counts = self.search_segments_device(q, self.offsets, int(k), prefilter)
-        idx, sims, counts = idx.cpu().numpy(), sims.cpu().numpy(), counts.cpu().numpy()
-        return [(idx[e, :counts[e]].astype(np.int64), sims[e, :counts[e]]) for e in range(len(self.lengths))]
+        packed, idx, _, _ = self._search_segments_packed(q, self.offsets, int(k), prefilter)
+        E, k = idx.shape
+        if E == 0:
+            return []
+        # one copy of the packed (idx | sims | counts) buffer into pinned memory instead of three synchronising .cpu() calls
+        host = self._readback_buffer(packed.numel())
+        host.copy_(packed, non_blocking=True)
+        torch.cuda.current_stream(packed.device).synchronize()
+        raw = host.numpy()
+        idx_h = raw[: E * k * 8].view(np.int64).reshape(E, k).copy()
+        sims_h = raw[E * k * 8: E * k * 12].view(np.float32).reshape(E, k).copy()
+        counts_h = raw[E * k * 12:].view(np.int32)
+        if int(counts_h.min()) == k:                             # every event has k rows: plain row views, no slicing
+            return list(zip(idx_h, sims_h))
+        return [(idx_h[e, :counts_h[e]], sims_h[e, :counts_h[e]]) for e in range(E)]
+
+    def _readback_buffer(self, nbytes: int) -> torch.Tensor:
+        buf = getattr(self, "_pinned", None)
+        if buf is None or buf.numel() < nbytes:
+            buf = self._pinned = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, pin_memory=True)
+        return buf[:nbytes]

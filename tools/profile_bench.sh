@@ -1,6 +1,7 @@
 #!/bin/bash
 # The two runs behind profiles/*_bench_*: bench.py under rocprofv3 --kernel-trace --stats (short), then plain (default).
-# Run on the GPU box from the repo root:  bash tools/profile_bench.sh <tag>   -> gpurun_out/<tag>_*
+# Run on the GPU box from the repo root:  bash tools/profile_bench.sh <tag>   -> gpurun_out/<tag>_* (kernel stats, stats by grid,
+# <tag>_roofline_recompute.json = the fractions of DESIGN section 4 from the trace alone: tools/roofline_recompute.py)
 set -e
 TAG=${1:-final}
 REPO=$PWD
@@ -26,6 +27,7 @@ with open(f"gpurun_out/{tag}_kernel_stats_by_grid.csv", "w") as f:
     for (k, wg), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
         w.writerow([k, wg, len(v), round(sum(v), 1), round(sum(v) / len(v), 2), round(min(v), 2), round(max(v), 2)])
 PY
+python3 tools/roofline_recompute.py "gpurun_out/${TAG}_kernel_trace.csv" "gpurun_out/${TAG}_roofline_recompute.json" > /dev/null
 rm -rf "gpurun_out/prof_$TAG" "gpurun_out/${TAG}_kernel_trace.csv"
 python3 bench.py > "gpurun_out/${TAG}_bench_line.json" 2> "gpurun_out/${TAG}_bench.err"
 tail -c 400 "gpurun_out/${TAG}_bench_line.json"
