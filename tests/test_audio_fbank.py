@@ -343,3 +343,39 @@ def test_wav_paths_fast_path_equals_clip_by_clip(tmp_path):
         for _ in range(2):                                       # the second call reuses the pinned buffer
             got = load_and_transform_audio_data_device([str(tmp_path / n) for n in names], torch.device("cuda"))
             assert got.shape == (len(names), 3, 1, 128, 204) and torch.equal(got, clip_by_clip(names)), names
+
+
+def test_fast_wav_reader_equals_scipy(tmp_path):
+    """_read_wav_raw: the RIFF walk returns exactly what scipy.io.wavfile.read does (dtype, shape, values, rate) for the formats it
+    takes itself -- 8 / 16 / 32-bit PCM and float32, mono and multi-channel, an odd-sized LIST chunk before the data -- and hands
+    everything else (float64, a non-wav file) to scipy."""
+    import struct
+    import warnings
+    from scipy.io import wavfile
+    from hippomm_amd.preprocess import _read_wav_raw
+    rng = np.random.default_rng(2)
+    cases = {"f32.wav": (16000, (rng.standard_normal(5001) * 0.2).astype(np.float32)),
+             "i16.wav": (16000, (rng.standard_normal(4000) * 3000).astype(np.int16)),
+             "i16_stereo.wav": (44100, (rng.standard_normal((3000, 2)) * 3000).astype(np.int16)),
+             "i32.wav": (8000, (rng.standard_normal(1000) * 1e8).astype(np.int32)),
+             "u8.wav": (8000, rng.integers(0, 256, 999, dtype=np.uint8)),
+             "f64.wav": (16000, rng.standard_normal(100)),                        # not taken by the fast route
+             "f32_3ch.wav": (48000, (rng.standard_normal((777, 3)) * 0.1).astype(np.float32))}
+    for name, (rate, x) in cases.items():
+        wavfile.write(tmp_path / name, rate, x)
+        got, got_rate = _read_wav_raw(str(tmp_path / name))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want_rate, want = wavfile.read(tmp_path / name)
+        assert got_rate == want_rate == rate and got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want), name
+    # a LIST chunk of odd size (padded to even) between fmt and data, as ffmpeg writes
+    raw = (tmp_path / "i16.wav").read_bytes()
+    at = raw.index(b"data")
+    padded = raw[:at] + b"LIST" + struct.pack("<I", 5) + b"abcde\x00" + raw[at:]
+    padded = padded[:4] + struct.pack("<I", len(padded) - 8) + padded[8:]
+    (tmp_path / "list.wav").write_bytes(padded)
+    got, _ = _read_wav_raw(str(tmp_path / "list.wav"))
+    assert np.array_equal(got, cases["i16.wav"][1])
+    (tmp_path / "bad.wav").write_bytes(b"not a wav file")
+    with pytest.raises(Exception):
+        _read_wav_raw(str(tmp_path / "bad.wav"))

@@ -240,3 +240,41 @@ def test_needed_window_holds_every_tap(h, w):
     assert x0 == bh[:, 0].min() and x0 + ww == (bh[:, 0] + bh[:, 1]).max() and (y0, y0 + wh) == (r0, r1)
     if (h, w) == (720, 1280):
         assert (x0, ww, y0, wh) == (275, 730, 0, 720)
+
+
+def test_cpu_quota_reads_the_cgroup_and_workers_follow_it(tmp_path, monkeypatch):
+    """cpu_quota(): scheduler affinity cut by the container's CFS quota (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us`); decode_workers
+    = that less two (the thread that feeds the GPU and the HIP runtime's own), HMM_DECODE_WORKERS overrides."""
+    import builtins
+    import os
+    real_open = builtins.open
+    files = {}
+
+    def fake_open(path, *a, **kw):
+        if isinstance(path, str) and path.startswith("/sys/fs/cgroup/"):
+            if path in files:
+                return real_open(files[path], *a, **kw)
+            raise OSError(path)
+        return real_open(path, *a, **kw)
+
+    def put(path, text):
+        f = tmp_path / path.strip("/").replace("/", "_")
+        f.write_text(text)
+        files[path] = str(f)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda _pid: set(range(256)), raising=False)
+    monkeypatch.delenv("HMM_DECODE_WORKERS", raising=False)
+    assert pp.cpu_quota() == 256.0 and pp.decode_workers() == 254                 # no cgroup files: the affinity
+    put("/sys/fs/cgroup/cpu.max", "1600000 100000\n")
+    assert pp.cpu_quota() == 16.0 and pp.decode_workers() == 14                   # the pool's pods
+    put("/sys/fs/cgroup/cpu.max", "max 100000\n")
+    assert pp.cpu_quota() == 256.0
+    files.clear()
+    put("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "350000\n")
+    put("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "100000\n")
+    assert pp.cpu_quota() == 3.5 and pp.decode_workers() == 3                     # cgroup v1, a fractional quota
+    put("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "-1\n")
+    assert pp.cpu_quota() == 256.0
+    monkeypatch.setenv("HMM_DECODE_WORKERS", "5")
+    assert pp.decode_workers() == 5
