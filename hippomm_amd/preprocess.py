@@ -150,7 +150,7 @@ _capsule_pointer = None
 _pools = {}
 _staging = {}
 _side_streams = {}
-_pipeline_lock = None
+_pipeline_lock = __import__("threading").Lock()     # one call at a time owns the ring, the side stream and the decode pool
 
 
 def cpu_quota() -> float:
@@ -240,7 +240,7 @@ def _jpeg_geometry(data: bytes):
     return None
 
 
-_direct = {"ok": None}                                             # None: not tried yet; False: this Pillow does not play along
+_direct = {"ok": None, "fails": 0}                                 # ok None: not verified yet; False: this Pillow does not play along
 _thread_images = None
 
 
@@ -286,8 +286,10 @@ def _decode_jpeg_direct(data: bytes, w: int, h: int, dst: np.ndarray, lib, windo
             _direct["ok"] = bool(np.array_equal(dst, np.asarray(_open_rgb_bytes(data))[y0:y0 + wh, x0:x0 + ww]))
             return _direct["ok"]
         return True
-    except Exception:                                              # noqa: BLE001 - internals moved: the ordinary route from now on
-        _direct["ok"] = False
+    except Exception:                                              # noqa: BLE001 - this frame takes the ordinary route ...
+        _direct["fails"] += 1                                      # (an image Pillow keeps in several blocks -- beyond 16 MB -- has no export)
+        if _direct["ok"] is not True and _direct["fails"] >= 3:    # ... and if it never worked, so does every later one
+            _direct["ok"] = False
         return False
 
 
@@ -408,9 +410,6 @@ def vision_pipeline(image_paths: Sequence[str], device=None, consume=None, worke
     x = torch.empty(n, 3, OUT, OUT, dtype=torch.float32, device=dev)
     if n == 0:
         return x
-    global _pipeline_lock
-    if _pipeline_lock is None:
-        _pipeline_lock = threading.Lock()
     workers = min(workers if workers > 0 else decode_workers(), n)
     first_chunk = max(2, min(first_chunk if first_chunk > 0 else min(workers, 8), n)) if n > 1 else 1
     upload_min = max(1, upload_min)

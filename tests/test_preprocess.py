@@ -278,3 +278,23 @@ def test_cpu_quota_reads_the_cgroup_and_workers_follow_it(tmp_path, monkeypatch)
     assert pp.cpu_quota() == 256.0
     monkeypatch.setenv("HMM_DECODE_WORKERS", "5")
     assert pp.decode_workers() == 5
+
+
+def test_a_frame_pillow_keeps_in_several_blocks_takes_the_copying_route(tmp_path):
+    """Beyond 16 MB of pixels Pillow has no single block to export: the direct decoder declines THAT frame (without switching itself
+    off once it has been verified) and the ordinary route copies -- the same pixels."""
+    from hippomm_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(6)
+    small = np.asarray(Image.fromarray(rng.integers(0, 256, (9, 13, 3), dtype=np.uint8)).resize((130, 90), Image.BICUBIC))
+    Image.fromarray(small).save(tmp_path / "small.jpg")
+    assert pp._decode_file(str(tmp_path / "small.jpg"), 130, 90, np.zeros((90, 130, 3), np.uint8), lib) is None and pp._direct["ok"] is True
+    big = np.asarray(Image.fromarray(rng.integers(0, 256, (18, 26, 3), dtype=np.uint8)).resize((2600, 1800), Image.BICUBIC))
+    Image.fromarray(big).save(tmp_path / "big.jpg", quality=80)
+    dst = np.zeros((1800, 2600, 3), np.uint8)
+    assert pp._decode_file(str(tmp_path / "big.jpg"), 2600, 1800, dst, lib) is None
+    assert np.array_equal(dst, np.asarray(Image.open(tmp_path / "big.jpg"))) and pp._direct["ok"] is True
+    win = (100, 50, 700, 600)
+    dst = np.zeros((600, 700, 3), np.uint8)
+    assert pp._decode_file(str(tmp_path / "big.jpg"), 2600, 1800, dst, lib, win) is None
+    assert np.array_equal(dst, np.asarray(Image.open(tmp_path / "big.jpg"))[50:650, 100:800])
