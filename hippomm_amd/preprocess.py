@@ -178,13 +178,17 @@ def cpu_quota() -> float:
 
 
 def decode_workers() -> int:
-    """Decode threads: the CPUs this process may use (cpu_quota) less two for the thread that feeds the GPU and the HIP
-    runtime's own; HMM_DECODE_WORKERS overrides."""
+    """Decode threads: the CPUs this process may use (cpu_quota) -- its share of them when torchrun started several ranks on the node
+    (LOCAL_WORLD_SIZE) -- less two for the thread that feeds the GPU and the HIP runtime's own; HMM_DECODE_WORKERS overrides."""
     import os
     env = os.environ.get("HMM_DECODE_WORKERS")
     if env:
         return max(1, int(env))
-    q = int(cpu_quota())
+    try:
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        ranks = 1
+    q = int(cpu_quota() / ranks)
     return max(1, q - 2 if q > 4 else q)
 
 

@@ -11,6 +11,7 @@ independent units, so the encoder shards with no data-path collective:
   * ``consolidate_sharded``     encode local frames -> all-gather -> global key-frame selection
                                 (every rank runs the 26.5 GFLOP selection redundantly: it is cheaper than
                                 broadcasting the result and keeps ranks symmetric);
+  * ``consolidate_paths_sharded``  the same from frame FILES: every rank runs extract_features on its shard of paths;
   * ``sharded_top_k``           row-sharded feature_search: local scan -> all-gather of k packed
                                 (sim,row) keys (8*k bytes/rank) -> merge under the same total order
                                 as the single-GPU scan, applied to GLOBAL row indices.
@@ -85,6 +86,27 @@ def consolidate_sharded(frames_local: torch.Tensor,
     local = encode_fn(frames_local) if frames_local.shape[0] > 0 else \
         torch.zeros(0, 1024, dtype=torch.float32, device=frames_local.device)
     feats = all_gather_embeddings(local, counts)
+    kept = (select_fn or _hip_select)(feats, similarity_threshold)
+    return feats, kept
+
+
+def consolidate_paths_sharded(frame_paths: Sequence[str],
+                              extract_fn: Callable[[Sequence[str]], torch.Tensor],
+                              similarity_threshold: float = 0.9,
+                              select_fn: Optional[Callable[[torch.Tensor, float], torch.Tensor]] = None,
+                              device: Optional[torch.device] = None):
+    """BASELINE cfg 5 from FILES: the time-ordered frame paths of a video are cut into contiguous shards, every rank runs the
+    reference's own call on its shard -- ``extract_fn(paths) = imagebind.extract_features({'vision': paths}, ['vision'])['vision']``
+    (hippocampal_memory.py:1180-1186), i.e. decode | upload + resize | tower on that rank's GPU and CPU share -- then ONE all-gather
+    and the global selection on every rank.  Returns (features (n,1024) of ALL frames in time order, kept global indices)."""
+    rank, ws = world()
+    bounds = shard_bounds(len(frame_paths), ws)
+    lo, hi = bounds[rank]
+    if hi > lo:
+        local = extract_fn(list(frame_paths[lo:hi]))
+    else:
+        local = torch.zeros(0, 1024, dtype=torch.float32, device=device or torch.device("cuda", torch.cuda.current_device()))
+    feats = all_gather_embeddings(local, [b - a for a, b in bounds])
     kept = (select_fn or _hip_select)(feats, similarity_threshold)
     return feats, kept
 

@@ -42,6 +42,15 @@ def _worker(rank, world, port, n_frames, q):
         # without counts (size exchange path)
         feats2 = sharding.all_gather_embeddings(feats_all[lo:hi])
         ok_gather2 = torch.equal(feats2, feats_all)
+        # from FILES: every rank gets the whole list of paths, embeds its own contiguous shard ("path" i stands for frame i)
+        paths = [f"frame_{i:05d}.jpg" for i in range(n_frames)]
+        seen = []
+
+        def extract(local_paths):
+            seen.extend(local_paths)
+            return feats_all[[int(p[6:11]) for p in local_paths]]
+        feats3, kept3 = sharding.consolidate_paths_sharded(paths, extract, 0.9, select_fn, device=torch.device("cpu"))
+        ok_gather2 = ok_gather2 and torch.equal(feats3, feats_all) and kept3.tolist() == want.tolist() and seen == paths[lo:hi]
 
         # sharded top-k over the same rows: local keys from the oracle's order key, merge on CPU
         query = torch.from_numpy(np.random.default_rng(5).standard_normal(1024).astype(np.float32))

@@ -203,3 +203,17 @@ def test_extract_features_from_files_equals_forward_of_load_data_bitwise(tmp_pat
                        model.extract_features({"vision": paths[:8]}, ["vision"])["vision"])
     assert model.extract_features({"vision": paths[:3] + [str(tmp_path / "nope.jpg")]}, ["vision"]) == {}
     assert "vision" in model.extract_features({"vision": paths[:3]}, ["vision"])             # and the next call works
+
+
+def test_sharded_consolidation_from_files_at_world_size_one(tmp_path):
+    """consolidate_paths_sharded (BASELINE cfg 5 from files) with no process group = the single-process formation: every frame's
+    embedding in time order and the kept indices of the selection oracle on them."""
+    from hippomm_amd.encoder import ImageBind
+    from hippomm_amd.sharding import consolidate_paths_sharded
+    paths, _ = _write_frames(tmp_path)
+    vspec = ib.reduced(ib.VISION_HUGE, DEPTH)
+    model = ImageBind(state_dict=ib.synthetic_state(vspec, seed=77, init="rich"), towers=("vision",), depth={"vision": DEPTH})
+    extract = lambda ps: model.extract_features({"vision": ps}, ["vision"])["vision"]
+    feats, kept = consolidate_paths_sharded(paths, extract, 0.9)
+    assert torch.equal(feats, extract(paths))
+    assert kept.cpu().tolist() == select_key_frames_oracle(feats.cpu().numpy(), None, 0.9).tolist()

@@ -298,3 +298,14 @@ def test_a_frame_pillow_keeps_in_several_blocks_takes_the_copying_route(tmp_path
     dst = np.zeros((600, 700, 3), np.uint8)
     assert pp._decode_file(str(tmp_path / "big.jpg"), 2600, 1800, dst, lib, win) is None
     assert np.array_equal(dst, np.asarray(Image.open(tmp_path / "big.jpg"))[50:650, 100:800])
+
+
+def test_decode_workers_share_the_quota_among_the_ranks_of_a_node(monkeypatch):
+    monkeypatch.delenv("HMM_DECODE_WORKERS", raising=False)
+    monkeypatch.setattr(pp, "cpu_quota", lambda: 16.0)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert pp.decode_workers() == 14
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")                  # torchrun --nproc-per-node 8 on a 16-CPU pod: two CPUs per rank
+    assert pp.decode_workers() == 2
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    assert pp.decode_workers() == 6
