@@ -6,7 +6,8 @@
 //            built once per store by hmm_shadow_store_build;
 //   pass 1   prefilter_topk_kernel streams the shadow: s~_r = dot(shadow_r, q) / ||q|| in fp32, block-local top-k of the s~ keys
 //            exactly as scan_topk_kernel keeps them (cosine_topk.hip);
-//   pass 2   prefilter_final_kernel (one workgroup): t = the k-th largest s~ over all blocks; every row whose exact similarity
+//   pass 2   prefilter_final_kernel (one workgroup): t = the k-th largest s~ over all blocks (or, when that already yields few
+//            candidates, its lower bound the k-th largest block maximum); every row whose exact similarity
 //            can be among the k largest has s~_r >= t - 2 eps (below); those rows are re-scored on the fp32 store with the
 //            arithmetic of scan_topk_kernel (exact_row_sim: same loads, same fma order, same wave reduction, same division) and
 //            the k best of them are the answer.
@@ -175,10 +176,6 @@ __global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* _
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     HMM_PF_STAMP(0);
     if (tid == 0) { n_cand = 0; n_sat = 0; n_hot = 0; *fallback_ticket = 0u; }          // the ticket of the conditional exact scan behind this kernel
-    // the k-th largest approximate key: the k lists with the largest maxima hold the k largest keys (every list keeps kk >= k
-    // entries).  (The k-th largest block MAXIMUM is a cheaper lower bound -- two dependent round trips fewer -- but when the k best
-    // rows sit in fewer than k blocks, as the frames of one scene do, it falls to the background level and thousands of rows
-    // become candidates: measured, 1/3 of the queries of a scene-structured store then took the exact-scan fallback.)
     const int n2 = pow2_at_least(n_blocks, 64);
     uint64_t own[kScanBlocks / 1024];                                         // this thread's block maxima, kept for the hot-list pass
 #pragma unroll
@@ -191,61 +188,85 @@ __global__ __launch_bounds__(1024) void prefilter_final_kernel(const uint64_t* _
     HMM_PF_STAMP(1);                                                          // maxima loaded
     top64_desc(mx, n2);
     HMM_PF_STAMP(2);                                                          // ... ranked
-    const int n_win = n_blocks < k ? n_blocks : k;
-    const int m2 = pow2_at_least(n_win * kk, 64);
-    for (int t = tid; t < m2; t += 1024) {
-        uint64_t key = 0ull;
-        if (t < n_win * kk) {
-            const uint64_t top = mx[t / kk];
-            if (top != 0ull) {
-                const int64_t row = (int64_t)(top & 0xFFFFFFFFull);
-                const int blk = (int)(((row >> 2) % n_waves) >> 2);           // rows are dealt four per wave
-                key = lists[(int64_t)blk * kk + (t % kk)];
+    HMM_PF_STAMP(3);                                                          // (3, 4: overwritten on the exact route)
+    HMM_PF_STAMP(4);
+    // Candidates under a threshold: the lists whose maximum reaches it, one wave per such list, one entry per lane; every entry at
+    // or above it is a candidate, a list whose LAST entry passes may have dropped some (saturated).  A wave loads its lists of a
+    // round (up to 8) before it looks at any of them: one memory latency per 128 hot lists instead of one per 16.
+    auto collect = [&](uint32_t thr) {
+#pragma unroll
+        for (int i = 0; i < kScanBlocks / 1024; ++i)
+            if (own[i] != 0ull && (uint32_t)(own[i] >> 32) >= thr) hot[atomicAdd(&n_hot, 1)] = (uint16_t)(tid + i * 1024);
+        __syncthreads();
+        constexpr int kHotUnroll = 8;
+        for (int h0 = wave; h0 < n_hot; h0 += 16 * kHotUnroll) {
+            uint64_t keys[kHotUnroll];
+#pragma unroll
+            for (int u = 0; u < kHotUnroll; ++u) {
+                const int h = h0 + 16 * u;
+                keys[u] = (h < n_hot && lane < kk) ? lists[(int64_t)hot[h] * kk + lane] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < kHotUnroll; ++u) {
+                if (h0 + 16 * u >= n_hot) break;                              // wave-uniform
+                const uint64_t key = keys[u];
+                const bool pass = key != 0ull && (uint32_t)(key >> 32) >= thr;
+                const unsigned long long mask = __ballot(pass);
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&n_cand, __popcll(mask));
+                base = __shfl(base, 0, 64);
+                if (pass) {
+                    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (pos < kPrefilterCap) cand_row[pos] = (uint32_t)(key & 0xFFFFFFFFull);
+                    if (lane == kk - 1) atomicAdd(&n_sat, 1);
+                }
             }
         }
-        s[t] = key;
+        __syncthreads();
+    };
+    auto threshold_below = [](uint64_t key) {                                 // NaN key -> 0xFFFFFFFF: only NaN rows pass
+        return order_bits(order_bits_inverse((uint32_t)(key >> 32)) - 2.0f * kPrefilterEps);
+    };
+    // QUICK route: the k-th largest block MAXIMUM is a lower bound of the k-th largest key (k lists hold a key that large), and it
+    // IS that key whenever the k best rows sit in k different lists -- the rule on a store without long runs of near-identical
+    // rows (1M random rows, k = 32: always).  Its candidate set contains the exact one; when it is small and no list is saturated
+    // the second ranking (gather the winners' lists, rank 2048 keys: 6 us) is skipped.
+    constexpr int kQuickCap = 128;
+    uint64_t kth = mx[k - 1];                                                 // k <= 64: inside the ranked front of mx
+    bool quick = false;
+    if (kth != 0ull) {                                                        // block-uniform (mx is shared)
+        collect(threshold_below(kth));
+        quick = n_sat == 0 && n_cand <= kQuickCap;
     }
-    __syncthreads();
-    HMM_PF_STAMP(3);                                                          // winners' lists gathered
-    top64_desc(s, m2);
-    HMM_PF_STAMP(4);                                                          // ... ranked: the k-th largest approximate key
-    const uint64_t kth = s[k - 1];                                            // 0 = fewer than k rows in all (launcher excludes it)
-    const float t_lo = order_bits_inverse((uint32_t)(kth >> 32)) - 2.0f * kPrefilterEps;
-    const uint32_t thr = order_bits(t_lo);                                    // NaN k-th -> 0xFFFFFFFF: only NaN rows pass
-    __syncthreads();
-    // lists that can hold a candidate: those whose maximum reaches the threshold
-#pragma unroll
-    for (int i = 0; i < kScanBlocks / 1024; ++i)
-        if (own[i] != 0ull && (uint32_t)(own[i] >> 32) >= thr) hot[atomicAdd(&n_hot, 1)] = (uint16_t)(tid + i * 1024);
-    __syncthreads();
-    // one wave per hot list, one entry per lane: every entry at or above the threshold is a candidate; a list whose LAST entry
-    // passes may have dropped some (saturated).  A wave loads its lists of a round (up to 8) before it looks at any of them: one
-    // memory latency per 128 hot lists instead of one per 16.
-    constexpr int kHotUnroll = 8;
-    for (int h0 = wave; h0 < n_hot; h0 += 16 * kHotUnroll) {
-        uint64_t keys[kHotUnroll];
-#pragma unroll
-        for (int u = 0; u < kHotUnroll; ++u) {
-            const int h = h0 + 16 * u;
-            keys[u] = (h < n_hot && lane < kk) ? lists[(int64_t)hot[h] * kk + lane] : 0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < kHotUnroll; ++u) {
-            if (h0 + 16 * u >= n_hot) break;                                  // wave-uniform
-            const uint64_t key = keys[u];
-            const bool pass = key != 0ull && (uint32_t)(key >> 32) >= thr;
-            const unsigned long long mask = __ballot(pass);
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&n_cand, __popcll(mask));
-            base = __shfl(base, 0, 64);
-            if (pass) {
-                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-                if (pos < kPrefilterCap) cand_row[pos] = (uint32_t)(key & 0xFFFFFFFFull);
-                if (lane == kk - 1) atomicAdd(&n_sat, 1);
+    if (!quick) {
+        // EXACT route: the k lists with the largest maxima hold the k largest keys (every list keeps kk >= k entries): rank them.
+        // (When the k best rows sit in fewer than k blocks, as the frames of one scene do, the block-maximum bound falls to the
+        // background level and thousands of rows pass it: a third of the queries of a scene-structured store would take the
+        // exact-scan fallback on that bound alone.)
+        __syncthreads();
+        if (tid == 0) { n_cand = 0; n_sat = 0; n_hot = 0; }
+        const int n_win = n_blocks < k ? n_blocks : k;
+        const int m2 = pow2_at_least(n_win * kk, 64);
+        for (int t = tid; t < m2; t += 1024) {
+            uint64_t key = 0ull;
+            if (t < n_win * kk) {
+                const uint64_t top = mx[t / kk];
+                if (top != 0ull) {
+                    const int64_t row = (int64_t)(top & 0xFFFFFFFFull);
+                    const int blk = (int)(((row >> 2) % n_waves) >> 2);       // rows are dealt four per wave
+                    key = lists[(int64_t)blk * kk + (t % kk)];
+                }
             }
+            s[t] = key;
         }
+        __syncthreads();
+        HMM_PF_STAMP(3);                                                      // winners' lists gathered
+        top64_desc(s, m2);
+        HMM_PF_STAMP(4);                                                      // ... ranked: the k-th largest approximate key
+        kth = s[k - 1];                                                       // 0 = fewer than k rows in all (launcher excludes it)
+        __syncthreads();
+        collect(threshold_below(kth));
     }
-    __syncthreads();
     HMM_PF_STAMP(5);                                                          // hot lists read, candidates listed
     const int m = n_cand;
     const bool fall = kth == 0ull || n_sat > 0 || m > kPrefilterCap;

@@ -1,8 +1,8 @@
 #!/bin/bash
-# GPU session r6q: the round's evidence at one commit -- full GPU suite, smoke(), bench.py under rocprofv3 + plain (profile_bench.sh:
+# GPU session r6u: the round's evidence at one commit -- full GPU suite, smoke(), bench.py under rocprofv3 + plain (profile_bench.sh:
 # kernel stats, stats by grid, roofline_recompute.json), the four PMC passes, the 8-rank rehearsal, the frozen dispatcher's recheck
 REPO=$PWD
-OUT=$REPO/gpurun_out/r6q
+OUT=$REPO/gpurun_out/r6u
 mkdir -p $OUT
 git rev-parse HEAD > $OUT/head.txt 2>/dev/null || true
 timeout 1800 python -m pytest tests -m gpu -x -q > $OUT/tests.log 2>&1
@@ -30,3 +30,12 @@ f = l["formation_from_files"]; print("formation", f["paths_32"]["ms_end_to_end"]
 a = l["audio_from_wav"]; print("audio", a["wav_1"], a["wav_16"]["ms_end_to_end"])
 print(l["reference_call_sizes"]["vision_frames_32_ms"], l["reference_call_sizes"]["vision_frame_1_ms"], l["reference_call_sizes"]["audio_segment_1_ms"], l["reference_call_sizes"]["text_question_1_ms"])
 PY
+cd tools && timeout 300 python prefilter_final_stamps_probe.py $OUT/prefilter_final_stamps.json > /dev/null; cd ..
+cd /tmp && export TMPDIR=/tmp
+rm -rf $OUT/prof
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -- python3 $REPO/tools/scan_trace_workload.py > $OUT/scan_traced.json 2> $OUT/scan_traced.err
+cd $REPO
+python3 tools/scan_trace_summarize.py "$(find $OUT/prof -name '*kernel_trace.csv' | head -1)" $OUT/scan_trace_summary.json | python3 -c "
+import json,sys; d=json.load(sys.stdin)
+for k,v in d.items(): print(k, v['period_us_median'], v['kernels_us_median'])"
+rm -rf $OUT/prof
