@@ -387,7 +387,8 @@ def _side_stream(dev):
 
 
 def vision_pipeline(image_paths: Sequence[str], device=None, consume=None, workers: int = 0, first_chunk: int = 0,
-                    upload_min: int = 8, depth: int = 1, max_chunk: int = 256, stats: dict = None) -> torch.Tensor:
+                    upload_min: int = 8, depth: int = 1, max_chunk: int = 256, stats: dict = None,
+                    poll_s: float = 0.0003, tail_wait: int = 0) -> torch.Tensor:
     """Image files -> (B,3,224,224) fp32 on `device`, bit-identical to the Pillow / torchvision host chain, as a pipeline:
     decode (host threads) | H2D + resize / crop / normalise (side stream) | consume(x, lo, hi) (caller's stream).
 
@@ -529,6 +530,8 @@ def vision_pipeline(image_paths: Sequence[str], device=None, consume=None, worke
                     hi = 0
                     if uploaded == n:
                         hi = min(n, issued + max_chunk)                   # everything is on its way: queue the rest behind the running range
+                    elif n - uploaded <= tail_wait and issued > 0:
+                        pass                                              # the last few frames are about to arrive: one range, not two
                     elif len(running) < depth and uploaded - issued >= need:
                         # the GPU has room: hand it the frames whose resize has FINISHED (a range waits for its last upload; while the
                         # tower is busy that wait is free, on an idle GPU it is not)
@@ -563,7 +566,7 @@ def vision_pipeline(image_paths: Sequence[str], device=None, consume=None, worke
                 if not progress and (futures is not None or sequential_next >= n):
                     with cond:                                            # decoders or the GPU have to move first
                         if state["prefix"] == prefix and state["error"] is None:
-                            cond.wait(0.0003 if running else 0.002)
+                            cond.wait(poll_s if running else 0.002)
             if consume is None:
                 cur.wait_event(batches[-1][1])
         finally:

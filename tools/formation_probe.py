@@ -76,15 +76,16 @@ def main():
         x = pp.load_and_transform_vision_data_device(ps, "cuda")
         fwd = bench.event_time_ms(lambda: tower.forward_into(x, emb), 5, warmup=2)
         want = emb.cpu()
-        grid = [(0, 0, 8, 1), (16, 0, 8, 1), (24, 0, 8, 1), (32, 0, 8, 1), (32, 16, 8, 1), (48, 0, 8, 1), (48, 16, 8, 1), (64, 16, 8, 1), (64, 32, 8, 1)]
-        for w, mc, um, mi in grid:
+        grid = [(0, 0, 8, 1, 0.0003, 0), (0, 0, 8, 1, 0.001, 0), (0, 0, 8, 1, 0.0003, 12), (0, 0, 8, 1, 0.001, 12), (0, 4, 8, 1, 0.001, 12),
+                (0, 0, 8, 1, 0.0003, 0), (0, 0, 8, 1, 0.001, 0), (0, 0, 8, 1, 0.0003, 12), (0, 0, 8, 1, 0.001, 12), (0, 4, 8, 1, 0.001, 12)]
+        for w, mc, um, mi, poll, tw in grid:
             if w > 2 * res["host_cpus"]:
                 continue
             stats = {}
 
             def call():
                 pp.vision_pipeline(ps, "cuda", lambda xx, lo, hi: tower.forward_into(xx[lo:hi], emb[lo:hi]), workers=w, first_chunk=mc,
-                                   upload_min=um, depth=mi, stats=stats)
+                                   upload_min=um, depth=mi, stats=stats, poll_s=poll, tail_wait=tw)
                 return emb.detach().cpu().numpy()
             call(); call()
             t = []
@@ -93,14 +94,14 @@ def main():
                 t0 = time.perf_counter()
                 got = call()
                 t.append((time.perf_counter() - t0) * 1e3)
-            rows.append({"frames": n, "workers": w, "first_chunk": mc, "upload_min": um, "depth": mi, "ms": round(median(t), 3),
+            rows.append({"frames": n, "workers": w, "first_chunk": mc, "upload_min": um, "depth": mi, "poll_s": poll, "tail_wait": tw, "ms": round(median(t), 3),
                          "ms_min": round(min(t), 3), "frames_per_s": round(n / median(t) * 1e3, 1), "ms_tensor_in_forward": round(fwd, 3),
                          "ranges": stats.get("chunks"), "same_bits": bool(np.array_equal(got, want.numpy()))})
             print(json.dumps(rows[-1]), flush=True)
     res["whole_call"] = rows
     # one traced call per setting: where the time goes
     traces = {}
-    for w, mc in ((0, 0), (32, 16)):
+    for w, mc in ((0, 0),):
         stats = {"trace": True}
         emb = torch.empty(256, 1024, device="cuda")
         for _ in range(3):
