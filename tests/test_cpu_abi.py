@@ -90,3 +90,12 @@ def test_product_never_imports_the_oracle():
     for path in (ROOT / "hippomm_amd").rglob("*.py"):
         text = path.read_text()
         assert "import oracle" not in text and "from oracle" not in text, path
+
+
+def test_graft_entry_build_passes_on_a_cpu_only_host():
+    """The driver's "does it build" check: __graft_entry__.build() compiles, loads and checks the ABI version it expects."""
+    import importlib
+    import sys
+    sys.path.insert(0, str(ROOT))
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
