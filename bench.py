@@ -507,6 +507,19 @@ def retrieval_bench(rows, do_cpu):
         t0 = time.perf_counter()
         top2 = ask_device_ranked()
         t2.append(time.perf_counter() - t0)
+    events.build_shadow()
+
+    def ask_device_ranked_prefilter():                       # the same through the bf16 shadow of the store (identical hits)
+        tower.forward_into(tok([question]).cuda(), emb)
+        return events.top_hits(emb[0], 5, 5, prefilter=True)
+
+    ask_device_ranked_prefilter()
+    t3 = []
+    for _ in range(7):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        top3 = ask_device_ranked_prefilter()
+        t3.append(time.perf_counter() - t0)
     t_tower = event_time_ms(lambda: tower.forward_into(tok([question]).cuda(), emb), 10, warmup=2, warm_ms=SCAN_WARM_MS)
     q = emb[0].clone()
     t_scan = event_time_ms(lambda: events.search_segments_device(q, events.offsets, 5), 30, warmup=2, warm_ms=SCAN_WARM_MS)
@@ -540,7 +553,11 @@ def retrieval_bench(rows, do_cpu):
                    "INTEGRATION.md's patch for hippocampal_memory.py:3143-3153 + :3275-3277 calls); ms_end_to_end_host_ranked = the same "
                    "with every event's hits read back and ranked in Python as the reference's loop does",
            "ms_end_to_end": round(sorted(t2)[len(t2) // 2] * 1e3, 3),
-           "ms_end_to_end_host_ranked": round(sorted(t)[len(t) // 2] * 1e3, 3), "ms_text_tower": round(t_tower, 3),
+           "ms_end_to_end_host_ranked": round(sorted(t)[len(t) // 2] * 1e3, 3),
+           "ms_end_to_end_bf16_prefilter": round(sorted(t3)[len(t3) // 2] * 1e3, 3),
+           "prefilter_hits_equal": [(e, i) for e, i, _ in top3] == [(e, i) for e, i, _ in top2] and
+           [v for _, _, v in top3] == [v for _, _, v in top2],
+           "ms_text_tower": round(t_tower, 3),
            "ms_per_event_scan_all_events": round(t_scan, 3), "events": n_events, "rows": n_events * per_event,
            "ms_per_event_scan_bf16_prefilter": round(t_scan_pre, 3), "prefilter_identical_to_fp32_scan": pre_same,
            "unchanged_reference_loop_ms_per_event": {"numpy_store_uploaded_per_call": round(ms_upload, 4),
@@ -1231,7 +1248,8 @@ def main():
         rp = line.get("scan", {}).get("retrieval", {}).get("parity_vs_oracle")
         if rp and not (rp["top5_of_first_200_events_equal"] and 1 - rp["text_embedding_cos"] <= 5e-5):
             bad.append("scan.retrieval.parity_vs_oracle")
-        if not line.get("scan", {}).get("retrieval", {}).get("prefilter_identical_to_fp32_scan", True):
+        if not line.get("scan", {}).get("retrieval", {}).get("prefilter_identical_to_fp32_scan", True) or \
+                not line.get("scan", {}).get("retrieval", {}).get("prefilter_hits_equal", True):
             bad.append("scan.retrieval.prefilter")
         for tag in ("weak_1M_rows_per_gpu", "strong_1M_rows_total"):
             if "scan" in line and not line["scan"].get(tag, {}).get("indices_match_torch_where_separated", True):
