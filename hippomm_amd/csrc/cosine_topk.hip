@@ -22,8 +22,9 @@ namespace hmm {
 constexpr int kFastK = 1024;      // chunk-tournament path handles k <= kFastK
 
 // sims[r] = dot(store[r], q) / (||store[r]|| * ||q||)     (vector_ops.py:178-182)
+// (at most six waves per SIMD, all eight loads of a row pair in flight: see scan_topk_kernel)
 template <bool NT>
-__global__ __launch_bounds__(256) void scan_sims_kernel(const float4* __restrict__ store,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 6))) void scan_sims_kernel(const float4* __restrict__ store,
                                                         int64_t n_rows,
                                                         const float4* __restrict__ query,
                                                         float* __restrict__ sims) {
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void scan_sims_kernel(const float4* __restrict
             for (int i = 0; i < 4; ++i) a[i] = ld16<NT>(p0 + i * 64);
 #pragma unroll
             for (int i = 0; i < 4; ++i) b[i] = ld16<NT>(p1 + i * 64);
+            __builtin_amdgcn_sched_barrier(0);              // all eight loads in flight before the first use (see scan_topk_body)
             float d0 = 0.f, s0 = 0.f, d1 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) fma4(d0, s0, a[i], q[i]);
@@ -172,6 +174,10 @@ __device__ __forceinline__ void scan_topk_body(const float4* __restrict__ store,
             for (int j = 0; j < 4; ++j) a[j] = ld16<NT>(p0 + j * 64);
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = ld16<NT>(p1 + j * 64);
+            // All eight loads leave before the first fma: the kernel lives on bytes in flight per wave.  Left to itself the
+            // scheduler waits for the first load alone before it issues the other seven, and under register pressure it folds the
+            // second half of the loads into the arithmetic (four in flight instead of eight).
+            __builtin_amdgcn_sched_barrier(0);
             float d0 = 0.f, s0 = 0.f, d1 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) fma4(d0, s0, a[j], q[j]);
@@ -192,7 +198,7 @@ __device__ __forceinline__ void scan_topk_body(const float4* __restrict__ store,
             const int n2 = pow2_at_least(n, 64);
             for (int t = n + threadIdx.x; t < n2; t += 256) cand[t] = 0ull;
             __syncthreads();
-            if (k <= 64) top64_desc(cand, n2);                          // block-uniform; leaves cand[0..63] sorted
+            if (k <= 64) top64_desc<false>(cand, n2);                   // block-uniform; leaves cand[0..63] sorted
             else         bitonic_sort_desc_rt(cand, n2);
             if (threadIdx.x == 0) count = n < k ? n : k;
             __syncthreads();
@@ -202,8 +208,12 @@ __device__ __forceinline__ void scan_topk_body(const float4* __restrict__ store,
     for (int t = threadIdx.x; t < k; t += 256) out[(int64_t)blockIdx.x * k + t] = t < n ? cand[t] : 0ull;
 }
 
+// At most SIX waves per SIMD.  The kernel is bound by HBM and wants many bytes in flight per wave (eight 16-byte loads per lane),
+// not many waves: at seven or eight waves per SIMD -- what 72 or 64 registers allow -- the same code streams 4 % slower (0.599 ->
+// 0.625 ms on 1M rows in one session; 4, 5 and 6 waves are equal; profiles/r6_scan_ab_variants.json).  Round 5's build sat at six by
+// the accident of needing 74 registers; round 6's leaner tournament dropped it to 66 and lost the 4 % until this limit was written down.
 template <bool NT>
-__global__ __launch_bounds__(256) void scan_topk_kernel(const float4* __restrict__ store, int64_t n_rows,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 6))) void scan_topk_kernel(const float4* __restrict__ store, int64_t n_rows,
                                                         const float4* __restrict__ query, int k,
                                                         uint64_t* __restrict__ out) {
     __shared__ uint64_t cand[kFusedCap];

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void prefilter_topk_kernel(const uint4* __rest
             const int n2 = pow2_at_least(n, 64);
             for (int t = n + threadIdx.x; t < n2; t += 256) cand[t] = 0ull;
             __syncthreads();
-            top64_desc(cand, n2);                                            // k <= 64 on this path
+            top64_desc<false>(cand, n2);                                     // k <= 64 on this path
             if (threadIdx.x == 0) count = n < k ? n : k;
             __syncthreads();
         }

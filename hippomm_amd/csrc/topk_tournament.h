@@ -59,16 +59,21 @@ __device__ __forceinline__ uint64_t wave_sort_desc(uint64_t v, int lane) {
 
 // s[0 .. n2): keys, n2 = 64 << m.  On return (after a workgroup barrier) s[0..63] holds the 64 largest, descending; the
 // rest of s is clobbered.  Called by every thread of the workgroup (blockDim.x a multiple of 64).
+template <bool PAIRS = true>
 __device__ __forceinline__ void top64_desc(uint64_t* s, int n2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     int chunks = n2 >> 6;
-    for (int c = wave; c < chunks; c += 2 * n_waves) {         // two chunks per wave at a time: two independent chains interleave
-        const int c1 = c + n_waves;
-        uint64_t v0 = s[c * 64 + lane], v1 = c1 < chunks ? s[c1 * 64 + lane] : 0ull;
-        bitonic_stages<2>(v0, lane);
-        bitonic_stages<2>(v1, lane);
-        s[c * 64 + lane] = v0;
-        if (c1 < chunks) s[c1 * 64 + lane] = v1;
+    if constexpr (PAIRS) {
+        for (int c = wave; c < chunks; c += 2 * n_waves) {     // two chunks per wave at a time: two independent chains interleave
+            const int c1 = c + n_waves;
+            uint64_t v0 = s[c * 64 + lane], v1 = c1 < chunks ? s[c1 * 64 + lane] : 0ull;
+            bitonic_stages<2>(v0, lane);
+            bitonic_stages<2>(v1, lane);
+            s[c * 64 + lane] = v0;
+            if (c1 < chunks) s[c1 * 64 + lane] = v1;
+        }
+    } else {                                                   // inside a streaming kernel: registers are the occupancy
+        for (int c = wave; c < chunks; c += n_waves) s[c * 64 + lane] = wave_sort_desc(s[c * 64 + lane], lane);
     }
     while (chunks > 1) {
         const int pairs = chunks >> 1;
