@@ -36,6 +36,7 @@ _SIGNATURES = {
     "hmm_cosine_topk_segmented_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "hmm_cosine_topk_segmented": (C.c_int, [c_ptr, C.c_int64, C.c_int, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr,
                                             c_ptr, C.c_size_t, c_ptr]),
+    "hmm_rank_segment_hits": (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "hmm_cosine_topk_multi_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "hmm_cosine_topk_multi": (C.c_int, [c_ptr, C.c_int64, C.c_int, c_ptr, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr,
                                         C.c_size_t, c_ptr]),

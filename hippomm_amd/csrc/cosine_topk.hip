@@ -441,6 +441,45 @@ struct ScanPlan {
     size_t off_sims, off_a, off_b, total;
 };
 
+// The global ranking behind the per-event scan (hippocampal_memory.py:3275-3277: the hits of all events in one list, sorted by
+// similarity, descending -- Python's sort is stable, so equal similarities stay in event order -- and the best `keep` kept).
+// One workgroup: a best-64 tournament over the (E, k) keys through a 4096-key window.  Key = (monotone(sim) << 32) | ~position, so
+// equal similarities rank by position (event, then rank inside the event) and every key is unique; slots beyond an event's count
+// are 0 and never chosen.  NaN similarities rank first, as they do inside an event.
+__global__ __launch_bounds__(1024) void rank_segment_hits_kernel(const int64_t* __restrict__ idx, const float* __restrict__ sims,
+                                                                 const int32_t* __restrict__ counts, int n_segments, int k, int keep,
+                                                                 int64_t* __restrict__ event_out, int64_t* __restrict__ row_out,
+                                                                 float* __restrict__ sim_out, int32_t* __restrict__ n_out) {
+    __shared__ uint64_t w[kChunk];
+    const int64_t total = (int64_t)n_segments * k;
+    int64_t base = 0;
+    int held = 0;
+    do {
+        const int take = kChunk - held;
+        for (int t = threadIdx.x; t < take; t += 1024) {
+            const int64_t pos = base + t;
+            uint64_t key = 0ull;
+            if (pos < total && (int)(pos % k) < counts[pos / k])
+                key = ((uint64_t)order_bits(sims[pos]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)pos);
+            w[held + t] = key;
+        }
+        base += take;
+        held = 64;
+        __syncthreads();
+        top64_desc(w, kChunk);
+    } while (base < total);
+    int n = 0;
+    for (int t = 0; t < keep; ++t) n += w[t] != 0ull;                        // every thread the same count (keys are sorted, zeros last)
+    if (threadIdx.x == 0) *n_out = n;
+    for (int t = threadIdx.x; t < keep; t += 1024) {
+        const bool valid = t < n;
+        const int64_t pos = valid ? (int64_t)(0xFFFFFFFFu - (uint32_t)(w[t] & 0xFFFFFFFFull)) : 0;
+        event_out[t] = valid ? pos / k : -1;
+        row_out[t] = valid ? idx[pos] : -1;
+        sim_out[t] = valid ? sims[pos] : 0.0f;
+    }
+}
+
 static int64_t next_pow2(int64_t x) { int64_t p = 1; while (p < x) p <<= 1; return p; }
 
 static ScanPlan make_plan(int64_t n, int k) {
@@ -688,6 +727,20 @@ extern "C" int hmm_cosine_topk_segmented(const float* store_dev, int64_t n_rows,
         HMM_LAUNCH_CHECK();
     }
     segment_topk_kernel<<<n_segments, 1024, 0, st>>>(sims, seg_offsets_dev, k, idx_out_dev, sim_out_dev, n_out_dev);
+    HMM_LAUNCH_CHECK();
+    return HMM_OK;
+}
+
+extern "C" int hmm_rank_segment_hits(const int64_t* idx_dev, const float* sims_dev, const int32_t* counts_dev, int n_segments, int k,
+                                     int keep, int64_t* event_out_dev, int64_t* row_out_dev, float* sim_out_dev, int32_t* n_out_dev,
+                                     hmm_stream_t stream) {
+    HMM_REQUIRE(idx_dev && sims_dev && counts_dev && event_out_dev && row_out_dev && sim_out_dev && n_out_dev, HMM_E_INVALID,
+                "rank_segment_hits: null pointer");
+    HMM_REQUIRE(n_segments >= 1 && k >= 1 && keep >= 1 && keep <= 64 && (int64_t)n_segments * k < (int64_t)0xFFFFFFFFll, HMM_E_INVALID,
+                "rank_segment_hits: need n_segments >= 1, k >= 1, 1 <= keep <= 64 and fewer than 2^32 hits (got %d x %d, keep %d)",
+                n_segments, k, keep);
+    rank_segment_hits_kernel<<<1, 1024, 0, static_cast<hipStream_t>(stream)>>>(idx_dev, sims_dev, counts_dev, n_segments, k, keep,
+                                                                              event_out_dev, row_out_dev, sim_out_dev, n_out_dev);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }

@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace hmm
 
-extern "C" int hmm_abi_version(void) { return 6; }      // 6: hmm_host_rgbx_to_rgb, hmm_host_arrow_rgbx_to_rgb
+extern "C" int hmm_abi_version(void) { return 7; }      // 6: hmm_host_rgbx_to_rgb, hmm_host_arrow_rgbx_to_rgb; 7: hmm_rank_segment_hits
 extern "C" const char* hmm_last_error(void) { return hmm::g_err; }
 
 // The kernels are written for one target: launch geometries assume 256 CUs in 8 XCDs (hmm_common.h) and the code objects are

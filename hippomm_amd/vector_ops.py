@@ -401,18 +401,31 @@ class EventStore(FeatureStore):
         back.  NaN similarities (zero-norm rows) rank first, as they do per event."""
         q = _query_to_device(query, self.rows.device)
         idx, sims, counts = self.search_segments_device(q, self.offsets, int(k), prefilter)
-        E = idx.shape[0]
-        if E == 0:
+        E, keep = idx.shape[0], int(keep)
+        if E == 0 or keep < 1:
             return []
-        slot = torch.arange(idx.shape[1], device=idx.device).unsqueeze(0)
-        valid = slot < counts.unsqueeze(1)
-        key = torch.where(valid, torch.nan_to_num(sims, nan=float("inf")), torch.full_like(sims, float("-inf"))).reshape(-1)
-        order = torch.sort(key, descending=True, stable=True).indices[: int(keep)]
-        order = order[valid.reshape(-1)[order]]                 # fewer than `keep` hits in the whole store
-        flat_idx, flat_sims = idx.reshape(-1)[order], sims.reshape(-1)[order]
-        # ONE read-back of the `keep` hits: event, row and similarity as doubles (exact for int32-range rows and fp32 similarities)
-        hits = torch.stack([(order // idx.shape[1]).double(), flat_idx.double(), flat_sims.double()]).cpu().numpy()
-        return [(int(e), int(r), float(np.float32(v))) for e, r, v in zip(hits[0], hits[1], hits[2])]
+        if keep > 64:                                           # beyond the ranking kernel's tournament width: torch's stable sort
+            slot = torch.arange(idx.shape[1], device=idx.device).unsqueeze(0)
+            valid = slot < counts.unsqueeze(1)
+            key = torch.where(valid, torch.nan_to_num(sims, nan=float("inf")), torch.full_like(sims, float("-inf"))).reshape(-1)
+            order = torch.sort(key, descending=True, stable=True).indices[:keep]
+            order = order[valid.reshape(-1)[order]]
+            flat_idx, flat_sims = idx.reshape(-1)[order], sims.reshape(-1)[order]
+            hits = torch.stack([(order // idx.shape[1]).double(), flat_idx.double(), flat_sims.double()]).cpu().numpy()
+            return [(int(e), int(r), float(np.float32(v))) for e, r, v in zip(hits[0], hits[1], hits[2])]
+        # one launch ranks the (E, k) hits (hmm_rank_segment_hits), one copy brings the `keep` best back: event | row | sim | count
+        lib = _lib.load()
+        packed = torch.empty(keep * 20 + 4, dtype=torch.uint8, device=idx.device)
+        ev = packed[: keep * 8].view(torch.int64)
+        row = packed[keep * 8: keep * 16].view(torch.int64)
+        val = packed[keep * 16: keep * 20].view(torch.float32)
+        n_out = packed[keep * 20:].view(torch.int32)
+        _lib.check(lib.hmm_rank_segment_hits(idx.data_ptr(), sims.data_ptr(), counts.data_ptr(), E, idx.shape[1], keep, ev.data_ptr(),
+                                             row.data_ptr(), val.data_ptr(), n_out.data_ptr(), _lib.stream_ptr()), "hmm_rank_segment_hits")
+        raw = packed.cpu().numpy()
+        n = int(raw[keep * 20:].view(np.int32)[0])
+        ev_h, row_h, val_h = raw[: keep * 8].view(np.int64), raw[keep * 8: keep * 16].view(np.int64), raw[keep * 16: keep * 20].view(np.float32)
+        return [(int(ev_h[t]), int(row_h[t]), float(val_h[t])) for t in range(n)]
 
     def top_k_per_event(self, query, k: int = 5, prefilter: bool = False):
         """[(indices int64[k_e], sims float32[k_e]) for every event], each exactly what

@@ -138,6 +138,14 @@ int    hmm_cosine_topk_segmented(const float* store_dev, int64_t n_rows, int dim
                                  int64_t* idx_out_dev, float* sim_out_dev, int32_t* n_out_dev,
                                  void* workspace_dev, size_t workspace_bytes, hmm_stream_t stream);
 
+/* The global ranking behind that loop (hippocampal_memory.py:3275-3277: the hits of every event in one list, sorted by similarity
+ * descending -- Python's stable sort: equal similarities stay in event order -- and the best ones kept).  Inputs: the three outputs of
+ * hmm_cosine_topk_segmented[_prefilter].  Outputs: the best keep' = min(keep, number of hits) hits, best first: event index, row
+ * within the event, similarity (-1 / -1 / 0 padded to `keep`), *n_out = keep'.  NaN similarities rank first.  keep <= 64. */
+int    hmm_rank_segment_hits(const int64_t* idx_dev, const float* sims_dev, const int32_t* counts_dev, int n_segments, int k,
+                             int keep, int64_t* event_out_dev, int64_t* row_out_dev, float* sim_out_dev, int32_t* n_out_dev,
+                             hmm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Consolidation similarity.  Replaces HippocampalMemory._select_key_frames(features, times,
  * similarity_threshold=0.9) (hippomm/core/hippocampal_memory.py:944-967; caller :855).

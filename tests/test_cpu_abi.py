@@ -58,7 +58,7 @@ def test_binding_table_matches_header():
     from hippomm_amd import _lib
     assert sorted(_lib._SIGNATURES) == _declared_symbols()
     lib = _lib.load()
-    assert lib.hmm_abi_version() == 6
+    assert lib.hmm_abi_version() == 7
     assert lib.hmm_cosine_topk_workspace_bytes(1_000_000, 32) > 4_000_000
     assert lib.hmm_gram_select_workspace_bytes(3600) > 3648 * 1024 * 4
 

@@ -137,3 +137,55 @@ def test_question_to_hits_over_250_events_and_120k_rows(query):
     assert len(store.top_hits(query, k=5, keep=100000)) == sum(min(5, n) for n in sizes)       # keep > all hits: every hit, ranked
     few = EventStore([events[0][:2], np.zeros((0, 1024), np.float32)])
     assert [(e, i) for e, i, _ in few.top_hits(query, 5, 5)] == [(0, int(i)) for i in top_k_cosine_similarity_oracle(query, events[0][:2], 5)[0]]
+
+
+def test_rank_segment_hits_is_pythons_stable_descending_sort():
+    """hmm_rank_segment_hits on hand-made (E, k) outputs of the per-event scan against the reference's rule -- every event's hits in one
+    list, `sorted(..., key=sim, reverse=True)` (stable: equal similarities stay in event order, then in rank order), the best kept:
+    ties inside and across events, -0.0 == +0.0, events with fewer than k hits, keep beyond the number of hits, NaN first, and more
+    keys than one tournament window."""
+    import ctypes as C
+    import torch
+    from hippomm_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(31)
+
+    def run(sims, counts, keep):
+        E, k = sims.shape
+        idx = torch.from_numpy(rng.integers(0, 10_000, (E, k))).cuda()
+        s, c = torch.from_numpy(sims).cuda(), torch.from_numpy(counts.astype(np.int32)).cuda()
+        ev, row = torch.empty(keep, dtype=torch.int64, device="cuda"), torch.empty(keep, dtype=torch.int64, device="cuda")
+        val, n = torch.empty(keep, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+        L.check(lib.hmm_rank_segment_hits(idx.data_ptr(), s.data_ptr(), c.data_ptr(), E, k, keep, ev.data_ptr(), row.data_ptr(), val.data_ptr(),
+                                          n.data_ptr(), None), "hmm_rank_segment_hits")
+        n = int(n.item())
+        flat = [(e, j) for e in range(E) for j in range(int(counts[e]))]
+        nan_first = [p for p in flat if np.isnan(sims[p])] + [p for p in flat if not np.isnan(sims[p])]
+        want = sorted(nan_first, key=lambda p: (0 if np.isnan(sims[p]) else 1, -float(sims[p]) if not np.isnan(sims[p]) else 0.0))[:keep]
+        assert n == len(want), (n, len(want))
+        got = list(zip(ev.cpu().tolist()[:n], row.cpu().tolist()[:n], val.cpu().numpy()[:n]))
+        idx_h = idx.cpu().numpy()
+        for (e, r, v), (we, wj) in zip(got, want):
+            assert e == we and r == idx_h[we, wj] and (v == sims[we, wj] or (np.isnan(v) and np.isnan(sims[we, wj]))), ((e, r, v), (we, wj))
+        assert ev.cpu().tolist()[n:] == [-1] * (keep - n)
+
+    k = 5
+    sims = rng.standard_normal((300, k)).astype(np.float32)
+    sims[:, :] = -np.sort(-sims, axis=1)                                   # per event descending, as the scan leaves them
+    sims[17, 0] = sims[3, 0] = sims[250, 0] = 9.0                          # a three-way tie across events: event order
+    sims[40, 1] = sims[40, 0]                                              # ... and inside an event: rank order
+    sims[5, 0], sims[6, 0] = 0.0, -0.0
+    counts = np.full(300, k)
+    counts[10], counts[11], counts[299] = 0, 2, 1
+    run(sims, counts, 5)
+    run(sims, counts, 64)
+    sims_nan = sims.copy()
+    sims_nan[100, 0] = sims_nan[7, 0] = np.nan                             # zero-norm rows: first, in event order
+    run(sims_nan, counts, 5)
+    run(sims[:2], np.array([1, 0]), 5)                                     # one hit in all: keep' = 1, the rest padded
+    big = -np.sort(-rng.standard_normal((2000, k)).astype(np.float32), axis=1)      # 10 000 keys: three tournament windows
+    big[1999, 0] = big[0, 0] = 7.5
+    run(big, np.full(2000, k), 5)
+    assert lib.hmm_rank_segment_hits(None, None, None, 1, 1, 1, None, None, None, None, None) == -1
+    x = torch.zeros(8, device="cuda")
+    assert lib.hmm_rank_segment_hits(x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 1, 65, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None) == -1
