@@ -686,8 +686,6 @@ constexpr DispatchRule kDispatchRules[] = {
      "vision:6;text:24,26", "r5_dispatch_audit_ab.json"},
     {"g_gemm_ring_peel_rows", 16, 0, "a last row tile of at most this many rows is peeled off a ring launch that it pushes past one tile per CU",
      "vision:3,4", "r5_ring_peel_ab_vision.json"},
-    {"g_gemm_small_by_r128", 1, 0, "a launch of at most one 128x128 tile per CU is a small launch whatever its count of 256x256 tiles",
-     "vision:12,24", "r5_small_by_r128_ab.json"},
 };
 constexpr bool rule_name_is(const char* a, const char* b) {
     while (*a && *a == *b) { ++a; ++b; }
@@ -891,7 +889,6 @@ int gemm_set_small_tiles(int tiles) {
     t_gemm_small_tiles = tiles;
     return prev;
 }
-HMM_RULE(g_gemm_small_by_r128)
 HMM_RULE(g_gemm_rect)
 HMM_RULE(g_gemm_rect64_min_t64)
 HMM_RULE(g_gemm_rect_rows)
@@ -989,12 +986,11 @@ int gemm_bf16(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int 
         // makes the main launch an exact number of rounds.
         const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
         const long tiles = (long)tiles_m * tiles_n;
-        // few 256x256 tiles (cls-only last block, head, small and mid-size batches): smaller tiles put more CUs to work.  Also
-        // when the launch is at most ONE 128 x 128 tile per CU: with rows just past a multiple of 256 (12 frames = 12 x 256 + 12
-        // rows) the 256-row count jumps a whole tile row early -- 65 ping-pong tiles for what is 250 ring tiles (24 frames on two
-        // chains 10.50 -> 9.94 ms, profiles/r5_small_by_r128_ab.json)
-        const long r128 = (long)((M + 127) / 128) * (N / 128);
-        if (tiles < t_gemm_small_tiles || (g_gemm_small_by_r128 && r128 <= kNumCU))
+        // few 256x256 tiles (cls-only last block, head, small and mid-size batches): smaller tiles put more CUs to work.
+        // (Round 5 also sent every launch of at most one 128 x 128 tile per CU here, whatever its count of 256-row tiles -- 24 frames on
+        // two chains -4.8 ... -6.2 % in five rechecks, -1.9 % in the one at round 6's final commit: under the 2 % a rule has to buy
+        // ON THAT RUN, so it went, profiles/r6_dispatch_recheck.json.)
+        if (tiles < t_gemm_small_tiles)
             return sliver_ok && sliver_wins(M, N, K, epi) ? launch_gemm_sliver_epi(A, W, bias, C, M, N, K, epi, st)
                                              : launch_gemm_small_epi(A, W, bias, C, M, N, K, epi, st);
         // peel p <= 2 row tiles when that leaves the main launch with a last round that is full or nearly full (>= 240 of 256
