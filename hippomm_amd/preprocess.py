@@ -146,6 +146,7 @@ def preprocess_frames_device(frames_u8: torch.Tensor) -> torch.Tensor:
 #   * the main thread hands every run of decoded frames to the GPU as soon as it exists: H2D + resize on a side stream, the
 #     consumer (the tower's forward) on the caller's stream behind an event, while the pool decodes the next frames.
 STAGING_BYTES = 512 << 20                          # pinned ring per frame size (more only to hold workers + 2 chunks)
+MAX_DECODE_THREADS = 16                            # see decode_workers
 _capsule_pointer = None
 _pools = {}
 _staging = {}
@@ -179,7 +180,8 @@ def cpu_quota() -> float:
 
 def decode_workers() -> int:
     """Decode threads: the CPUs this process may use (cpu_quota) -- its share of them when torchrun started several ranks on the node
-    (LOCAL_WORLD_SIZE) -- less two for the thread that feeds the GPU and the HIP runtime's own; HMM_DECODE_WORKERS overrides."""
+    (LOCAL_WORLD_SIZE) -- less two for the thread that feeds the GPU and the HIP runtime's own, and at most MAX_DECODE_THREADS;
+    HMM_DECODE_WORKERS overrides."""
     import os
     env = os.environ.get("HMM_DECODE_WORKERS")
     if env:
@@ -189,7 +191,10 @@ def decode_workers() -> int:
     except ValueError:
         ranks = 1
     q = int(cpu_quota() / ranks)
-    return max(1, q - 2 if q > 4 else q)
+    # never more than 16: the threads share one interpreter lock, and past ~16 of them the hand-overs cost more than the cores give
+    # (256 frames: 105 ms on 16 threads, 122-139 ms on 32-128, profiles/r6_formation_probe_first.json; one burst of 32 frames: 6.1 ms
+    # on 16, 5.7 on 32, profiles/r6_decode_burst.json)
+    return max(1, min(q - 2 if q > 4 else q, MAX_DECODE_THREADS))
 
 
 def _decode_pool(workers: int):

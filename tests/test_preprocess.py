@@ -265,7 +265,7 @@ def test_cpu_quota_reads_the_cgroup_and_workers_follow_it(tmp_path, monkeypatch)
     monkeypatch.setattr(builtins, "open", fake_open)
     monkeypatch.setattr(os, "sched_getaffinity", lambda _pid: set(range(256)), raising=False)
     monkeypatch.delenv("HMM_DECODE_WORKERS", raising=False)
-    assert pp.cpu_quota() == 256.0 and pp.decode_workers() == 254                 # no cgroup files: the affinity
+    assert pp.cpu_quota() == 256.0 and pp.decode_workers() == 16                  # no cgroup files: the affinity; threads capped at 16
     put("/sys/fs/cgroup/cpu.max", "1600000 100000\n")
     assert pp.cpu_quota() == 16.0 and pp.decode_workers() == 14                   # the pool's pods
     put("/sys/fs/cgroup/cpu.max", "max 100000\n")
