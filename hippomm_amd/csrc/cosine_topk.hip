@@ -20,6 +20,14 @@
 namespace hmm {
 
 constexpr int kFastK = 1024;      // chunk-tournament path handles k <= kFastK
+// Workgroups of the streaming kernels.  A pass over the store is bound by HBM, and HBM is saturated by bandwidth x latency of bytes in
+// flight (~7 TB/s x 1.5 us = ~11 MB): scan_topk_kernel keeps 8 KB per wave in flight, so ~1536 waves = 384 workgroups are enough, and
+// MORE of them stream slower -- 2048 workgroups 0.613 ms, 512: 0.598, 384: 0.579 (= the 0.885 of 8 TB/s a pure reader gets), 336:
+// 0.597, 256: 0.721 on 1M rows in one session, a smooth bowl around 384 on two boxes (profiles/r6_scan_blocks.json).  Until round 6
+// the grid was "eight workgroups per CU" by habit.  The similarity pass (scan_sims_kernel, 32 rows per wave and visit) has no such
+// optimum (0.651 ... 0.72 ms, 2048 among the best) and keeps its grid.
+HMM_TUNABLE(int, g_scan_blocks, kNumCU * 3 / 2)   // scan_topk_kernel
+HMM_TUNABLE(int, g_sims_blocks, kScanBlocks)      // scan_sims_kernel
 
 // sims[r] = dot(store[r], q) / (||store[r]|| * ||q||)     (vector_ops.py:178-182)
 // (at most six waves per SIMD, all eight loads of a row pair in flight: see scan_topk_kernel)
@@ -535,7 +543,7 @@ static int run_scan(const float* store, int64_t n, int dim, const float* query, 
 
     int64_t waves_needed = (n + 1) / 2;
     int blocks = (int)((waves_needed + 3) / 4);
-    if (blocks > kScanBlocks) blocks = kScanBlocks;
+    if (blocks > g_scan_blocks) blocks = g_scan_blocks;
     *k_eff = p.k_eff;
 
     if (!p.full_sort && n > kChunk && p.k_eff <= kFusedK) {
@@ -678,7 +686,7 @@ extern "C" int hmm_op_scan_sims(const float* store_dev, int64_t n_rows, const fl
                                  hmm_stream_t stream) {
     int64_t waves_needed = (n_rows + 1) / 2;
     int blocks = (int)((waves_needed + 3) / 4);
-    if (blocks > kScanBlocks) blocks = kScanBlocks;
+    if (blocks > g_sims_blocks) blocks = g_sims_blocks;
     scan_sims_kernel<true><<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
         reinterpret_cast<const float4*>(store_dev), n_rows, reinterpret_cast<const float4*>(query_dev), sims_dev);
     HMM_LAUNCH_CHECK();
@@ -691,7 +699,7 @@ extern "C" int hmm_op_scan_topk_only(const float* store_dev, int64_t n_rows, con
     HMM_REQUIRE(k >= 1 && k <= kFusedK, HMM_E_INVALID, "scan_topk_only: k out of range");
     int64_t waves_needed = (n_rows + 1) / 2;
     int blocks = (int)((waves_needed + 3) / 4);
-    if (blocks > kScanBlocks) blocks = kScanBlocks;
+    if (blocks > g_scan_blocks) blocks = g_scan_blocks;
     scan_topk_kernel<true><<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
         reinterpret_cast<const float4*>(store_dev), n_rows, reinterpret_cast<const float4*>(query_dev), k, cand_dev);
     HMM_LAUNCH_CHECK();
@@ -721,7 +729,7 @@ extern "C" int hmm_cosine_topk_segmented(const float* store_dev, int64_t n_rows,
     if (n_rows > 0) {
         int64_t waves_needed = (n_rows + 1) / 2;
         int blocks = (int)((waves_needed + 3) / 4);
-        if (blocks > kScanBlocks) blocks = kScanBlocks;
+        if (blocks > g_sims_blocks) blocks = g_sims_blocks;
         scan_sims_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store_dev), n_rows,
                                                        reinterpret_cast<const float4*>(query_dev), sims);
         HMM_LAUNCH_CHECK();

@@ -26,6 +26,10 @@
 
 namespace hmm {
 
+// Workgroups of the bf16 passes (see g_scan_blocks in cosine_topk.hip): the shadow pass does more arithmetic per byte and wants more
+// waves than the fp32 scan, 768 workgroups: 0.3327 -> 0.3199 ms per query (640: 0.3202, 512: 0.328, 384: 0.390; profiles/r6_scan_blocks.json)
+HMM_TUNABLE(int, g_prefilter_blocks, kNumCU * 3)       // prefilter_topk_kernel
+HMM_TUNABLE(int, g_prefilter_sims_blocks, kScanBlocks) // prefilter_sims_kernel
 constexpr float kPrefilterEps = 0.0040f;
 constexpr int kPrefilterCap = 1024;           // candidate rows pass 2 re-scores itself (16 waves)
 constexpr int kPrefilterMaxK = 64;
@@ -466,7 +470,7 @@ static PrefilterPlan prefilter_plan(int64_t n, int k) {
     p.off_lists = align_up(exact, 256);
     int64_t waves_needed = (n + 3) / 4;
     int blocks = (int)((waves_needed + 3) / 4);
-    p.blocks = blocks > kScanBlocks ? kScanBlocks : blocks;
+    p.blocks = blocks > g_prefilter_blocks ? g_prefilter_blocks : blocks;
     p.off_maxima = p.off_lists + align_up((size_t)kScanBlocks * (size_t)kPrefilterMaxK * 8, 256);
     p.off_flag = p.off_maxima + align_up((size_t)kScanBlocks * 8, 256);          // int flag, then the fallback's unsigned ticket
     p.total = p.off_flag + 256;
@@ -565,7 +569,7 @@ extern "C" int hmm_cosine_topk_segmented_prefilter(const float* store_dev, const
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* sims = static_cast<float*>(workspace_dev);
     int64_t blocks = (n_rows + 127) / 128;                                  // 4 waves x 32 rows
-    if (blocks > kScanBlocks) blocks = kScanBlocks;
+    if (blocks > g_prefilter_sims_blocks) blocks = g_prefilter_sims_blocks;
     prefilter_sims_kernel<<<(unsigned)blocks, 256, 0, st>>>(static_cast<const uint4*>(shadow_dev), n_rows,
                                                             reinterpret_cast<const float4*>(query_dev), sims);
     HMM_LAUNCH_CHECK();
