@@ -228,13 +228,19 @@ def mfma_roofline(flops: float, ms: float, scope: str) -> dict:
             "flops_accounting": "nominal (reference's un-folded patch conv, every block on every token)"}
 
 
-def event_time_ms(fn, iters, warmup=2, warm_ms=0.0):
-    """Mean ms per call over `iters` back-to-back calls (HIP events on the current stream) after `warmup` calls and, when
+def event_time_ms(fn, iters, warmup=2, warm_ms=0.0, groups=1, detail=None):
+    """ms per call over `iters` back-to-back calls (HIP events on the current stream) after `warmup` calls and, when
     `warm_ms` > 0, after at least that many milliseconds of the same calls: sub-millisecond kernels timed right after the
     device has idled -- a read-back, host work -- run their first 10-30 launches 10-25 % slow while the clocks come back up
     (tools/multi_thermal_probe.py, profiles/r5_multi_thermal.json: the 16-query scan 0.85 / 0.70 / 0.67 / 0.66 / 0.65 ms over its
     first five groups of ten launches).  That, not the kernel, was round 4's batched_16_queries 0.672 -> 0.765 ms: the leg had
-    moved behind a read-back and was timed over launches 4-13."""
+    moved behind a read-back and was timed over launches 4-13.
+
+    `groups` > 1: the same `iters` calls, still back to back with no synchronisation in between, with an event after every
+    iters / groups of them; the MEDIAN group is returned and `detail` receives every group, the mean and what the host spent
+    enqueueing a call.  Round 6 traced why the exact query read 0.611-0.644 ms here and 0.582-0.584 ms in the kernel trace of the
+    same session: one ~1.3-ms stall somewhere in the first leg after the CPU oracle's parity check, in three full runs of three
+    and in none of seven runs without that check (profiles/LABNOTES_r6.md section 5) -- not a cost of a query."""
     for _ in range(warmup):
         fn()
     if warm_ms > 0:                      # never for a leg that contains a collective: the number of calls would differ per rank
@@ -245,13 +251,22 @@ def event_time_ms(fn, iters, warmup=2, warm_ms=0.0):
                 fn()
             torch.cuda.synchronize()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
+    per = max(1, iters // groups)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(groups + 1)]
+    evs[0].record()
+    t0 = time.perf_counter()
+    for g in range(groups):
+        for _ in range(per):
+            fn()
+        evs[g + 1].record()
+    host_s = time.perf_counter() - t0
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    by_group = [evs[g].elapsed_time(evs[g + 1]) / per for g in range(groups)]
+    mean = evs[0].elapsed_time(evs[groups]) / (per * groups)
+    if detail is not None:
+        detail.update({"groups_ms": [round(x, 4) for x in by_group], "mean_ms": round(mean, 4),
+                       "host_us_per_call": round(host_s / (per * groups) * 1e6, 1)})
+    return _median(by_group) if groups > 1 else mean
 
 
 def profile_summary(pattern: str, kernel: str):
@@ -388,29 +403,33 @@ def scan_bench(do_cpu):
         rows[s:s + 125_000] = blk / blk.norm(dim=1, keepdim=True)
     q = torch.randn(1024, generator=torch.Generator(device="cuda").manual_seed(43), device="cuda")
     store = FeatureStore(rows)
-    ms_query = event_time_ms(lambda: store.search_device(q, SCAN_K), 50, warmup=3, warm_ms=SCAN_WARM_MS)
+    d_query, d_kernel, d_pre, d_multi = {}, {}, {}, {}
+    ms_query = event_time_ms(lambda: store.search_device(q, SCAN_K), 50, warmup=3, warm_ms=SCAN_WARM_MS, groups=5, detail=d_query)
     # the streaming kernel alone (dominant kernel of the scan)
     lib = L.load()
     cand = torch.empty(2048 * SCAN_K, dtype=torch.int64, device="cuda")
     ms_kernel = event_time_ms(lambda: L.check(lib.hmm_op_scan_topk_only(rows.data_ptr(), SCAN_ROWS, q.data_ptr(), SCAN_K,
                                                                         cand.data_ptr(), L.stream_ptr()), "scan"), 50,
-                             warm_ms=SCAN_WARM_MS)
+                             warm_ms=SCAN_WARM_MS, groups=5, detail=d_kernel)
     algo_bytes = SCAN_ROWS * 4096.0
     traffic, src = profile_summary("r*_scan_pmc_summary.json", "scan_topk_kernel")
     out = {
         "metric": "cosine-scan GB/s (feature_search, 1M x 1024 fp32 store, top-32, 1 query)",
         "value": round(algo_bytes / ms_query / 1e6, 1), "unit": "GB/s", "ms_per_query": round(ms_query, 4),
-        "dtype": "f32",
+        "timing": "every scan leg: 50 back-to-back calls, one HIP event after every 10, no synchronisation in between; the MEDIAN "
+                  "group is the figure, all five groups and the mean of the 50 are in *_timing (see event_time_ms)",
+        "ms_per_query_timing": d_query, "dtype": "f32",
         "roofline": {"bound": "hbm", "kernel": "scan_topk_kernel", "achieved": round(algo_bytes / ms_kernel / 1e6, 1),
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(algo_bytes / ms_kernel / 1e6 / PEAK_HBM_GBS, 4),
                      "traffic": traffic, "traffic_source": src,
-                     "bytes_per_launch": algo_bytes, "ms_per_launch": round(ms_kernel, 4)},
+                     "bytes_per_launch": algo_bytes, "ms_per_launch": round(ms_kernel, 4), "ms_per_launch_timing": d_kernel},
     }
     # the same query through the bf16 shadow store (reported SEPARATELY, against 2048 B per row; the headline above is
     # the fp32 store): candidates from one pass over the shadow, exact fp32 re-score -> the same indices and similarity bits
     store.build_shadow()
     stats = torch.zeros(2, dtype=torch.int32, device="cuda")
-    ms_pre = event_time_ms(lambda: store.search_prefiltered_device(q, SCAN_K, stats), 50, warmup=3, warm_ms=SCAN_WARM_MS)
+    ms_pre = event_time_ms(lambda: store.search_prefiltered_device(q, SCAN_K, stats), 50, warmup=3, warm_ms=SCAN_WARM_MS, groups=5,
+                           detail=d_pre)
     i_ex, s_ex = store.search_device(q, SCAN_K)
     i_pre, s_pre = store.search_prefiltered_device(q, SCAN_K, stats)
     shadow_bytes = SCAN_ROWS * 2048.0
@@ -418,7 +437,7 @@ def scan_bench(do_cpu):
     out["prefilter_bf16_shadow"] = {
         "what": "hmm_cosine_topk_prefilter: bf16 shadow (row / ||row||, 2048 B per row) streamed for candidates under a proven "
                 "error bound, exact fp32 re-score of the candidates; same result as the fp32 scan",
-        "ms_per_query": round(ms_pre, 4), "speedup_vs_fp32_scan": round(ms_query / ms_pre, 2),
+        "ms_per_query": round(ms_pre, 4), "ms_per_query_timing": d_pre, "speedup_vs_fp32_scan": round(ms_query / ms_pre, 2),
         "identical_to_fp32_scan": bool(torch.equal(i_ex, i_pre) and torch.equal(s_ex.view(torch.int32), s_pre.view(torch.int32))),
         "candidates_rescored": int(stats[0].item()), "saturated_lists": int(stats[1].item()),
         "roofline": {"bound": "hbm", "kernel": "prefilter_topk_kernel (+ prefilter_final_kernel)", "scope": "whole query",
@@ -428,8 +447,8 @@ def scan_bench(do_cpu):
         "extra_hbm_bytes_held": shadow_bytes}
     # batched questions: 16 queries per pass over the same store
     q16 = torch.randn(16, 1024, generator=torch.Generator(device="cuda").manual_seed(44), device="cuda")
-    ms_multi = event_time_ms(lambda: store.search_multi_device(q16, SCAN_K), 50, warmup=3, warm_ms=SCAN_WARM_MS)
-    out["batched_16_queries"] = {"ms_per_pass": round(ms_multi, 4), "us_per_query": round(ms_multi / 16 * 1e3, 1),
+    ms_multi = event_time_ms(lambda: store.search_multi_device(q16, SCAN_K), 50, warmup=3, warm_ms=SCAN_WARM_MS, groups=5, detail=d_multi)
+    out["batched_16_queries"] = {"ms_per_pass": round(ms_multi, 4), "ms_per_pass_timing": d_multi, "us_per_query": round(ms_multi / 16 * 1e3, 1),
                                  "store_read_GBps": round(algo_bytes / ms_multi / 1e6, 1),
                                  "hbm_frac": round(algo_bytes / ms_multi / 1e6 / PEAK_HBM_GBS, 4),
                                  "speedup_vs_16_single_scans": round(16 * ms_query / ms_multi, 2)}

@@ -614,7 +614,7 @@ int cosine_topk_if(const int* run_if, unsigned* ticket, const float* store, int6
     HMM_REQUIRE(ws_bytes >= p.total, HMM_E_WORKSPACE, "cosine_topk_if: workspace %zu < required %zu", ws_bytes, p.total);
     int64_t waves_needed = (n + 1) / 2;
     int blocks = (int)((waves_needed + 3) / 4);
-    if (blocks > kScanBlocks) blocks = kScanBlocks;
+    if (blocks > g_scan_blocks) blocks = g_scan_blocks;
     exact_scan_fallback_kernel<<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n, reinterpret_cast<const float4*>(query),
                                                        k, reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + p.off_a), run_if, ticket,
                                                        idx_out, sim_out, n_out);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU session r6u: the round's evidence at one commit -- full GPU suite, smoke(), bench.py under rocprofv3 + plain (profile_bench.sh:
-# kernel stats, stats by grid, roofline_recompute.json), the four PMC passes, the 8-rank rehearsal, the frozen dispatcher's recheck
+# kernel stats, stats by grid, roofline_recompute.json), the four PMC passes, the 8-rank rehearsal, the prefilter stress, the frozen dispatcher's recheck
 REPO=$PWD
 OUT=$REPO/gpurun_out/r6u
 mkdir -p $OUT
@@ -15,6 +15,7 @@ PREFIX=r6 timeout 1500 bash tools/pmc_passes.sh r6 > $OUT/pmc.log 2>&1
 echo "pmc rc=$?"; tail -3 $OUT/pmc.log
 timeout 900 python tools/rehearse_n8.py $OUT/rehearsal_8_ranks.json > $OUT/rehearse.log 2>&1
 echo "rehearse rc=$?"; tail -2 $OUT/rehearse.log
+timeout 900 python tools/prefilter_stress.py 1000 > $OUT/stress.log 2>&1; echo "stress rc=$?"; tail -4 $OUT/stress.log
 timeout 1500 python tools/dispatch_audit_probe.py --check $OUT/dispatch_recheck.json > $OUT/recheck.log 2>&1
 echo "recheck rc=$?"; grep '"keep"' $OUT/recheck.log | python3 -c "
 import sys, json
