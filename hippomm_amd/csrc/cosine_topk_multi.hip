@@ -40,7 +40,10 @@ constexpr int kMSlices = 8;             // K slices per tile: 128 floats each
 constexpr int kMPiece = 1056;           // LDS bytes per DMA piece: 2 rows x 512 B + 32 B (bank rotation between pieces)
 constexpr int kMSliceBytes = 8 * kMPiece;
 constexpr int kMRing = 4;               // slices per wave: one being read, three in flight (96 KiB per CU).  Depth is not the limit:
-                                        // 2 / 3 / 4 slices 0.648 / 0.654 / 0.651 ms per pass in one session (round 6)
+                                        // 2 / 3 / 4 slices 0.648 / 0.654 / 0.651 ms per pass in one session (round 6).  Nor are the
+                                        // MFMAs (VALU dot products instead: 0.653) or, mostly, the 512-B pieces: the bare DMA stream of
+                                        // this kernel, nothing read or computed, runs 0.613 against 0.650.  1-KiB pieces (one row x 256
+                                        // floats per instruction, 16-KiB slices) leave room for only two slices per wave: 0.683
 constexpr int kMCap = 128;              // candidate keys per query and workgroup (>= k + kMRows, power of two)
 constexpr int kMMaxK = 64;              // k*k <= 4096 for the one-kernel finish
 constexpr int kMMaxBlocks = 2048;
