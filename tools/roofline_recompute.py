@@ -55,8 +55,13 @@ def main():
                 add(f"{label} ({tag})", sub, wg, 2.0 * (wg // tn * 256) * n_dim * k_dim, "flop", split)
         add(f"fused in_proj + attention ({tag})", "qkv_attention_kernel<hmm::VisionGeo>", frames * H,
             frames * H * (2.0 * T * 3 * DH * D + 4.0 * T * T * DH), "flop")
-    add("scan_topk_kernel (1M x 1024 fp32 rows)", "scan_topk_kernel", 2048, 1_000_000 * 4096.0, "bytes")
-    add("prefilter_topk_kernel (1M x 1024 bf16 shadow rows)", "prefilter_topk_kernel", 2048, 1_000_000 * 2048.0, "bytes")
+    def full_pass_grid(sub):                                    # the grid of the symbol's 1M-row passes = the one with the most launches
+        grids = {w: len(v) for (n, w), v in acc.items() if sub in n and w > 64}      # (384 / 768 workgroups since round 6, 2048 before)
+        return max(grids, key=grids.get) if grids else 0
+
+    add("scan_topk_kernel (1M x 1024 fp32 rows)", "scan_topk_kernel", full_pass_grid("scan_topk_kernel"), 1_000_000 * 4096.0, "bytes")
+    add("prefilter_topk_kernel (1M x 1024 bf16 shadow rows)", "prefilter_topk_kernel", full_pass_grid("prefilter_topk_kernel"),
+        1_000_000 * 2048.0, "bytes")
     add("scan_multi_kernel (1M rows once for 16 queries)", "scan_multi_kernel", 256, 1_000_000 * 4096.0, "bytes")
     add("topk_final_kernel (finish of the exact query)", "topk_final_kernel", 1, 2048 * 32 * 8.0, "bytes")
     add("prefilter_final_kernel (finish of the prefilter query)", "prefilter_final_kernel", 1, 2048 * 64 * 8.0, "bytes")
