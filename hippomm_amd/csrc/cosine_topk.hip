@@ -25,9 +25,14 @@ constexpr int kFastK = 1024;      // chunk-tournament path handles k <= kFastK
 // MORE of them stream slower -- 2048 workgroups 0.613 ms, 512: 0.598, 384: 0.579 (= the 0.885 of 8 TB/s a pure reader gets), 336:
 // 0.597, 256: 0.721 on 1M rows in one session, a smooth bowl around 384 on two boxes (profiles/r6_scan_blocks.json).  Until round 6
 // the grid was "eight workgroups per CU" by habit.  The similarity pass (scan_sims_kernel, 32 rows per wave and visit) has no such
-// optimum (0.651 ... 0.72 ms, 2048 among the best) and keeps its grid.
+// optimum (0.651 ... 0.72 ms, 2048 among the best; the kernel alone 0.601-0.619 ms from 256 to 2048 workgroups) and keeps its grid.
 HMM_TUNABLE(int, g_scan_blocks, kNumCU * 3 / 2)   // scan_topk_kernel
 HMM_TUNABLE(int, g_sims_blocks, kScanBlocks)      // scan_sims_kernel
+HMM_TUNABLE(int, g_small_segment_rows, 1024)      // mean rows per event up to which the small per-event selection kernels run
+
+bool segments_are_small(int64_t n_rows, int n_segments, int k) {
+    return k <= 64 && n_segments >= 1 && n_rows <= (int64_t)n_segments * g_small_segment_rows;
+}
 
 // sims[r] = dot(store[r], q) / (||store[r]|| * ||q||)     (vector_ops.py:178-182)
 // (at most six waves per SIMD, all eight loads of a row pair in flight: see scan_topk_kernel)
@@ -57,7 +62,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 6))) voi
         float mine = 0.f;                                   // lane l < 32 ends up with the similarity of row base + l
         const int64_t left = n_rows - base;
         const int pairs = left >= 32 ? 16 : (int)((left + 1) >> 1);      // wave-uniform
-        for (int j = 0; j < pairs; ++j) {
+        for (int jj = 0; jj < pairs; ++jj) {
+            // Waves start at different pairs of their 128-KB groups: walked in step, every wave of the chip is at the same offset of
+            // a 128-KB-strided group at the same time (0.6109 -> 0.6046 ms per pass, same bits; profiles/r6_sims_stagger.json)
+            const int j = pairs == 16 ? ((jj + (int)(wave & 15)) & 15) : jj;
             const int64_t r = base + 2 * j;
             const bool two = (r + 1) < n_rows;
             const float4* p0 = store + r * 256 + lane;
@@ -404,13 +412,17 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(const uint64_t* __restr
 // matrix with k=5 (hippocampal_memory.py:3143-3153, :3294-3304).  Here all events live concatenated in one
 // resident store with a row-offset table: one streaming pass computes every similarity, then one workgroup
 // per event selects that event's top-k (indices are rows WITHIN the event) under the same total order.
-// Events larger than a chunk are folded in pieces, carrying the running best k.
+// Events larger than a chunk are folded in pieces, carrying the running best k.  Two shapes of the same code: 4096 keys / 1024
+// threads, and -- when the events average at most g_small_segment_rows rows and k <= 64 -- 1024 keys / 256 threads: a selection is a
+// chain of dependent steps whatever the thread count, and eight small workgroups fit a CU where two large ones do (2000 events of
+// 500 rows: one round of workgroups instead of four).  Same result: keys are unique and totally ordered.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void segment_topk_kernel(const float* __restrict__ sims,
+template <int CHUNK, int THREADS>
+__global__ __launch_bounds__(THREADS) void segment_topk_kernel(const float* __restrict__ sims,
                                                             const int64_t* __restrict__ seg_off, int k,
                                                             int64_t* __restrict__ idx_out, float* __restrict__ sim_out,
                                                             int32_t* __restrict__ n_out) {
-    __shared__ uint64_t s[kChunk];
+    __shared__ uint64_t s[CHUNK];
     const int e = blockIdx.x, tid = threadIdx.x;
     const int64_t lo = seg_off[e], hi = seg_off[e + 1];
     const int64_t n = hi - lo;
@@ -419,10 +431,10 @@ __global__ __launch_bounds__(1024) void segment_topk_kernel(const float* __restr
     int64_t base = 0;
     do {
         const int64_t left = n - base;
-        const int take = (int)(left < (int64_t)(kChunk - have) ? left : (int64_t)(kChunk - have));
+        const int take = (int)(left < (int64_t)(CHUNK - have) ? left : (int64_t)(CHUNK - have));
         const int total = have + take;
         const int n2 = pow2_at_least(total, 64);
-        for (int t = have + tid; t < n2; t += 1024) {
+        for (int t = have + tid; t < n2; t += THREADS) {
             uint64_t key = 0ull;
             if (t < total) {
                 const int64_t r = base + (t - have);
@@ -437,7 +449,7 @@ __global__ __launch_bounds__(1024) void segment_topk_kernel(const float* __restr
         base += take;
     } while (base < n);
     if (tid == 0) n_out[e] = k_out;
-    for (int t = tid; t < k; t += 1024) {
+    for (int t = tid; t < k; t += THREADS) {
         const bool ok = t < k_out;
         idx_out[(int64_t)e * k + t] = ok ? (int64_t)(s[t] & 0xFFFFFFFFull) : -1;
         sim_out[(int64_t)e * k + t] = ok ? order_bits_inverse((uint32_t)(s[t] >> 32)) : 0.0f;
@@ -734,7 +746,10 @@ extern "C" int hmm_cosine_topk_segmented(const float* store_dev, int64_t n_rows,
                                                        reinterpret_cast<const float4*>(query_dev), sims);
         HMM_LAUNCH_CHECK();
     }
-    segment_topk_kernel<<<n_segments, 1024, 0, st>>>(sims, seg_offsets_dev, k, idx_out_dev, sim_out_dev, n_out_dev);
+    if (segments_are_small(n_rows, n_segments, k))
+        segment_topk_kernel<kSmallSegChunk, 256><<<n_segments, 256, 0, st>>>(sims, seg_offsets_dev, k, idx_out_dev, sim_out_dev, n_out_dev);
+    else
+        segment_topk_kernel<kChunk, 1024><<<n_segments, 1024, 0, st>>>(sims, seg_offsets_dev, k, idx_out_dev, sim_out_dev, n_out_dev);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }

@@ -371,11 +371,12 @@ __global__ __launch_bounds__(256) void prefilter_sims_kernel(const uint4* __rest
 // fp32 store (exact_row_sim) and the k best of those are the event's answer -- what segment_topk_kernel returns on the exact
 // similarities.  More candidates than the buffer holds (an event of near-identical rows): every row of the event is re-scored.
 constexpr int kSegCandCap = 1024;
-__global__ __launch_bounds__(1024) void segment_prefilter_kernel(const float* __restrict__ sims, const int64_t* __restrict__ seg_off,
+template <int CHUNK, int THREADS>
+__global__ __launch_bounds__(THREADS) void segment_prefilter_kernel(const float* __restrict__ sims, const int64_t* __restrict__ seg_off,
                                                                  int k, const float4* __restrict__ store,
                                                                  const float4* __restrict__ query, int64_t* __restrict__ idx_out,
                                                                  float* __restrict__ sim_out, int32_t* __restrict__ n_out) {
-    __shared__ uint64_t s[kChunk];
+    __shared__ uint64_t s[CHUNK];
     __shared__ uint32_t cand[kSegCandCap];
     __shared__ int n_cand;
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(1024) void segment_prefilter_kernel(const float* __
     if (tid == 0) n_cand = 0;
     if (n <= 0) {                                                  // block-uniform
         if (tid == 0) n_out[e] = 0;
-        for (int t = tid; t < k; t += 1024) { idx_out[(int64_t)e * k + t] = -1; sim_out[(int64_t)e * k + t] = 0.0f; }
+        for (int t = tid; t < k; t += THREADS) { idx_out[(int64_t)e * k + t] = -1; sim_out[(int64_t)e * k + t] = 0.0f; }
         return;
     }
     // ---- the k-th largest approximate key of the event (pieces of a chunk, carrying the running best k) ---------------------
@@ -395,10 +396,10 @@ __global__ __launch_bounds__(1024) void segment_prefilter_kernel(const float* __
         int64_t base = 0;
         do {
             const int64_t left = n - base;
-            const int take = (int)(left < (int64_t)(kChunk - have) ? left : (int64_t)(kChunk - have));
+            const int take = (int)(left < (int64_t)(CHUNK - have) ? left : (int64_t)(CHUNK - have));
             const int total = have + take;
             const int n2 = pow2_at_least(total, 64);
-            for (int t = have + tid; t < n2; t += 1024) {
+            for (int t = have + tid; t < n2; t += THREADS) {
                 uint64_t key = 0ull;
                 if (t < total) {
                     const int64_t r = base + (t - have);
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(1024) void segment_prefilter_kernel(const float* __
     }
     __syncthreads();
     // ---- candidates ---------------------------------------------------------------------------------------------------------
-    for (int64_t r = tid; r < n; r += 1024) {
+    for (int64_t r = tid; r < n; r += THREADS) {
         if (order_bits(sims[lo + r]) >= thr) {
             const int pos = atomicAdd(&n_cand, 1);
             if (pos < kSegCandCap) cand[pos] = (uint32_t)r;
@@ -439,11 +440,11 @@ __global__ __launch_bounds__(1024) void segment_prefilter_kernel(const float* __
     int64_t base = 0;
     do {
         const int64_t left = m - base;
-        const int take = (int)(left < (int64_t)(kChunk - have) ? left : (int64_t)(kChunk - have));
+        const int take = (int)(left < (int64_t)(CHUNK - have) ? left : (int64_t)(CHUNK - have));
         const int total = have + take;
         const int n2 = pow2_at_least(total, 64);
-        for (int t = total + tid; t < n2; t += 1024) s[t] = 0ull;
-        for (int c = wave; c < take; c += 16) {                    // wave-uniform trip count per wave
+        for (int t = total + tid; t < n2; t += THREADS) s[t] = 0ull;
+        for (int c = wave; c < take; c += THREADS / 64) {                    // wave-uniform trip count per wave
             const int64_t r = all_rows ? base + c : (int64_t)cand[base + c];
             const float sim = exact_row_sim(store + (lo + r) * 256 + lane, q, q_len);
             if (lane == 0) s[have + c] = ((uint64_t)order_bits(sim) << 32) | (uint64_t)(uint32_t)r;
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(1024) void segment_prefilter_kernel(const float* __
         base += take;
     } while (base < m);
     if (tid == 0) n_out[e] = k_out;
-    for (int t = tid; t < k; t += 1024) {
+    for (int t = tid; t < k; t += THREADS) {
         const bool ok = t < k_out;
         idx_out[(int64_t)e * k + t] = ok ? (int64_t)(s[t] & 0xFFFFFFFFull) : -1;
         sim_out[(int64_t)e * k + t] = ok ? order_bits_inverse((uint32_t)(s[t] >> 32)) : 0.0f;
@@ -573,8 +574,14 @@ extern "C" int hmm_cosine_topk_segmented_prefilter(const float* store_dev, const
     prefilter_sims_kernel<<<(unsigned)blocks, 256, 0, st>>>(static_cast<const uint4*>(shadow_dev), n_rows,
                                                             reinterpret_cast<const float4*>(query_dev), sims);
     HMM_LAUNCH_CHECK();
-    segment_prefilter_kernel<<<n_segments, 1024, 0, st>>>(sims, seg_offsets_dev, k, reinterpret_cast<const float4*>(store_dev),
-                                                          reinterpret_cast<const float4*>(query_dev), idx_out_dev, sim_out_dev, n_out_dev);
+    if (segments_are_small(n_rows, n_segments, k))          // the two shapes of segment_topk_kernel, for the same reason
+        segment_prefilter_kernel<kSmallSegChunk, 256><<<n_segments, 256, 0, st>>>(
+            sims, seg_offsets_dev, k, reinterpret_cast<const float4*>(store_dev), reinterpret_cast<const float4*>(query_dev), idx_out_dev,
+            sim_out_dev, n_out_dev);
+    else
+        segment_prefilter_kernel<kChunk, 1024><<<n_segments, 1024, 0, st>>>(
+            sims, seg_offsets_dev, k, reinterpret_cast<const float4*>(store_dev), reinterpret_cast<const float4*>(query_dev), idx_out_dev,
+            sim_out_dev, n_out_dev);
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }

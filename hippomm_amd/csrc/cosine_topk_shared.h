@@ -72,6 +72,10 @@ __device__ __forceinline__ void exact_row_sim4(const float4* const (&row_lane)[4
     }
 }
 
+// The per-event selection kernels come in two shapes (see segment_topk_kernel): true when the small one serves this call.
+constexpr int kSmallSegChunk = 1024;
+bool segments_are_small(int64_t n_rows, int n_segments, int k);
+
 int cosine_topk_if(const int* run_if, unsigned* ticket, const float* store, int64_t n, const float* query, int k, int64_t* idx_out,
                    float* sim_out, int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t st);
 

@@ -159,6 +159,7 @@ def _events(sizes, seed):
 
 
 @pytest.mark.parametrize("sizes,k", [([300, 1, 0, 57, 5, 4096, 4097, 2], 5), ([9000, 3, 12000], 32), ([40] * 200, 5), ([500] * 64, 5),
+                                     ([1500, 2, 0, 700, 1025, 64, 3000, 1], 5), ([200] * 50, 64),
                                      ([5000], 64), ([5000], 100)])
 def test_per_event_prefilter_equals_the_exact_per_event_scan(sizes, k):
     """hmm_cosine_topk_segmented_prefilter vs hmm_cosine_topk_segmented: identical indices, similarity bits and counts for every

@@ -17,6 +17,8 @@ def _events(sizes, seed):
 @pytest.mark.parametrize("sizes,k", [([300, 1, 0, 57, 5, 4096, 4097, 2], 5),       # reference's k=5; empty / tiny events
                                      ([9000, 3, 12000], 32),                        # events larger than one chunk
                                      ([40] * 200, 5),                               # many small events
+                                     ([1500, 2, 0, 700, 1025, 64, 3000, 1], 5),     # small mean (the 1024-key kernels), events above it
+                                     ([200] * 50, 64),                              # ... at their largest k
                                      ([5000], 1024)])
 def test_per_event_matches_reference_per_event_calls(sizes, k):
     from hippomm_amd.vector_ops import EventStore
