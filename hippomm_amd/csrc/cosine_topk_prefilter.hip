@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256) void prefilter_sims_kernel(const uint4* __rest
         float mine = 0.f;                                         // lane l < 32: s~ of row base + l
         const int64_t left = n_rows - base;
         const int steps = left >= 32 ? 8 : (int)((left + 3) >> 2);           // wave-uniform
-        for (int j = 0; j < steps; ++j) {
+        for (int jj = 0; jj < steps; ++jj) {
+            const int j = steps == 8 ? ((jj + (int)(wave & 7)) & 7) : jj;    // not in step with every other wave: see scan_sims_kernel
             const int64_t r = base + 4 * j;
             uint4 x[4][2];
 #pragma unroll
