@@ -471,23 +471,49 @@ __global__ __launch_bounds__(1024) void rank_segment_hits_kernel(const int64_t* 
                                                                  int64_t* __restrict__ event_out, int64_t* __restrict__ row_out,
                                                                  float* __restrict__ sim_out, int32_t* __restrict__ n_out) {
     __shared__ uint64_t w[kChunk];
+    __shared__ int n_cand;
     const int64_t total = (int64_t)n_segments * k;
-    int64_t base = 0;
-    int held = 0;
-    do {
-        const int take = kChunk - held;
-        for (int t = threadIdx.x; t < take; t += 1024) {
-            const int64_t pos = base + t;
-            uint64_t key = 0ull;
-            if (pos < total && (int)(pos % k) < counts[pos / k])
-                key = ((uint64_t)order_bits(sims[pos]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)pos);
-            w[held + t] = key;
+    auto key_at = [&](int64_t pos) -> uint64_t {
+        if (pos < total && (int)(pos % k) < counts[pos / k])
+            return ((uint64_t)order_bits(sims[pos]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)pos);
+        return 0ull;
+    };
+    if (total <= (int64_t)1024 * (kChunk / 64)) {
+        // Quick route (2000 events x 5 hits: 33 -> ~10 us): every thread's largest key -> the keep-th largest of those 1024 maxima, M,
+        // is a lower bound of the keep-th largest key, and since keys are unique exactly `keep` threads hold keys >= M: the at most
+        // keep x ceil(total / 1024) <= 4096 keys at or above M contain the answer and are ranked alone.
+        uint64_t best = 0ull;
+        for (int64_t pos = threadIdx.x; pos < total; pos += 1024) {
+            const uint64_t key = key_at(pos);
+            best = key > best ? key : best;
         }
-        base += take;
-        held = 64;
+        w[threadIdx.x] = best;
+        if (threadIdx.x == 0) n_cand = 0;
         __syncthreads();
-        top64_desc(w, kChunk);
-    } while (base < total);
+        top64_desc(w, 1024);
+        const uint64_t m = w[keep - 1];                                      // 0: fewer than `keep` threads hold a hit at all
+        __syncthreads();
+        for (int64_t pos = threadIdx.x; pos < total; pos += 1024) {
+            const uint64_t key = key_at(pos);
+            if (key != 0ull && key >= m) w[atomicAdd(&n_cand, 1)] = key;     // m == 0: fewer than keep x ceil(total / 1024) hits exist
+        }
+        __syncthreads();
+        const int n2 = pow2_at_least(n_cand, 64);
+        for (int t = n_cand + threadIdx.x; t < n2; t += 1024) w[t] = 0ull;
+        __syncthreads();
+        top64_desc(w, n2);
+    } else {
+        int64_t base = 0;
+        int held = 0;
+        do {
+            const int take = kChunk - held;
+            for (int t = threadIdx.x; t < take; t += 1024) w[held + t] = key_at(base + t);
+            base += take;
+            held = 64;
+            __syncthreads();
+            top64_desc(w, kChunk);
+        } while (base < total);
+    }
     int n = 0;
     for (int t = 0; t < keep; ++t) n += w[t] != 0ull;                        // every thread the same count (keys are sorted, zeros last)
     if (threadIdx.x == 0) *n_out = n;

@@ -143,7 +143,7 @@ def test_rank_segment_hits_is_pythons_stable_descending_sort():
     """hmm_rank_segment_hits on hand-made (E, k) outputs of the per-event scan against the reference's rule -- every event's hits in one
     list, `sorted(..., key=sim, reverse=True)` (stable: equal similarities stay in event order, then in rank order), the best kept:
     ties inside and across events, -0.0 == +0.0, events with fewer than k hits, keep beyond the number of hits, NaN first, and more
-    keys than one tournament window."""
+    keys than one tournament window (the quick route up to 65 536 keys, the windowed pass beyond)."""
     import ctypes as C
     import torch
     from hippomm_amd import _lib as L
@@ -186,6 +186,10 @@ def test_rank_segment_hits_is_pythons_stable_descending_sort():
     big = -np.sort(-rng.standard_normal((2000, k)).astype(np.float32), axis=1)      # 10 000 keys: three tournament windows
     big[1999, 0] = big[0, 0] = 7.5
     run(big, np.full(2000, k), 5)
+    run(big, np.full(2000, k), 64)
+    huge = -np.sort(-rng.standard_normal((14000, k)).astype(np.float32), axis=1)    # 70 000 keys: beyond the quick route (65 536)
+    huge[13999, 0] = huge[1, 0] = 8.5
+    run(huge, np.full(14000, k), 5)
     assert lib.hmm_rank_segment_hits(None, None, None, 1, 1, 1, None, None, None, None, None) == -1
     x = torch.zeros(8, device="cuda")
     assert lib.hmm_rank_segment_hits(x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 1, 65, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None) == -1
