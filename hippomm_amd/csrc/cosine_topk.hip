@@ -28,6 +28,7 @@ constexpr int kFastK = 1024;      // chunk-tournament path handles k <= kFastK
 // optimum (0.651 ... 0.72 ms, 2048 among the best; the kernel alone 0.601-0.619 ms from 256 to 2048 workgroups) and keeps its grid.
 HMM_TUNABLE(int, g_scan_blocks, kNumCU * 3 / 2)   // scan_topk_kernel
 HMM_TUNABLE(int, g_sims_blocks, kScanBlocks)      // scan_sims_kernel
+HMM_TUNABLE(int, g_sims_deferred, 1)               // scan_sims_deferred_kernel wherever the store fits it
 HMM_TUNABLE(int, g_small_segment_rows, 1024)      // mean rows per event up to which the small per-event selection kernels run
 
 bool segments_are_small(int64_t n_rows, int n_segments, int k) {
@@ -88,6 +89,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 6))) voi
         }
         if (lane < 32 && base + lane < n_rows) sims[base + lane] = mine;
     }
+}
+
+// The same similarities with scan_topk_kernel's row dealing (pair p belongs to wave p % n_waves: at any moment the waves of the chip
+// read one contiguous window of the store) and NO store inside the loop: lane l of two registers keeps the results of iteration
+// 64 j + l, and the wave writes everything it computed when it has read its last row.  Stores mixed into the read stream are what
+// scan_sims_kernel pays for: groups of 32 rows with one 128-B line of results each 0.606 ms per pass, the same without its stores
+// 0.589, this dealing with an 8-byte store per pair in the loop 0.621, without any 0.573 (scan_topk_kernel) -- and deferred: see
+// profiles/r6_sims_deferred.json.  Same arithmetic per row, same bits.
+constexpr int kSimsHeld = 8;
+template <bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 6))) void scan_sims_deferred_kernel(
+        const float4* __restrict__ store, int64_t n_rows, const float4* __restrict__ query, float* __restrict__ sims) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    float4 q[4];
+    float qs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        q[j] = query[j * 64 + lane];
+        qs = fmaf(q[j].x, q[j].x, qs); qs = fmaf(q[j].y, q[j].y, qs);
+        qs = fmaf(q[j].z, q[j].z, qs); qs = fmaf(q[j].w, q[j].w, qs);
+    }
+    const float q_len = sqrtf(wave_sum(qs));
+    // an epoch = 64 kSimsHeld iterations (1M rows on the scan's grid: one epoch of 326); larger stores write once per epoch
+    for (int64_t it0 = 0; (wave + it0 * n_waves) * 2 < n_rows; it0 += 64 * kSimsHeld) {
+    float h0[kSimsHeld], h1[kSimsHeld];
+#pragma unroll
+    for (int j = 0; j < kSimsHeld; ++j) { h0[j] = 0.f; h1[j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < kSimsHeld; ++j) {
+        for (int l = 0; l < 64; ++l) {
+            const int64_t r = (wave + (it0 + j * 64 + l) * n_waves) * 2;
+            if (r >= n_rows) break;                                          // wave-uniform; every later iteration is past the end too
+            const bool two = (r + 1) < n_rows;
+            const float4* p0 = store + r * 256 + lane;
+            const float4* p1 = p0 + (two ? 256 : 0);
+            float4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = ld16<NT>(p0 + i * 64);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = ld16<NT>(p1 + i * 64);
+            __builtin_amdgcn_sched_barrier(0);                               // all eight loads in flight before the first use
+            float d0 = 0.f, s0 = 0.f, d1 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fma4(d0, s0, a[i], q[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fma4(d1, s1, b[i], q[i]);
+            d0 = wave_sum(d0); s0 = wave_sum(s0);
+            d1 = wave_sum(d1); s1 = wave_sum(s1);
+            const float v0 = d0 / (sqrtf(s0) * q_len), v1 = d1 / (sqrtf(s1) * q_len);
+            h0[j] = lane == l ? v0 : h0[j];
+            h1[j] = lane == l ? v1 : h1[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kSimsHeld; ++j) {
+        const int64_t r = (wave + (it0 + j * 64 + lane) * n_waves) * 2;
+        if (r + 1 < n_rows)  *reinterpret_cast<float2*>(sims + r) = make_float2(h0[j], h1[j]);
+        else if (r < n_rows) sims[r] = h0[j];
+    }
+    }
+}
+
+// All similarities of a store into sims[] (scan_sims_kernel is what the probe build's knob compares against).
+static void launch_scan_sims(const float* store, int64_t n, const float* query, float* sims, hipStream_t st) {
+    int64_t waves_needed = (n + 1) / 2;
+    int blocks = (int)((waves_needed + 3) / 4);
+    if (g_sims_deferred) {
+        if (blocks > g_scan_blocks) blocks = g_scan_blocks;
+        scan_sims_deferred_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n,
+                                                                reinterpret_cast<const float4*>(query), sims);
+        return;
+    }
+    if (blocks > g_sims_blocks) blocks = g_sims_blocks;
+    scan_sims_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n, reinterpret_cast<const float4*>(query), sims);
 }
 
 // Descending bitonic sort of N keys in LDS by NT threads.
@@ -609,8 +686,7 @@ static int run_scan(const float* store, int64_t n, int dim, const float* query, 
         return HMM_OK;
     }
 
-    scan_sims_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n,
-                                                   reinterpret_cast<const float4*>(query), sims);
+    launch_scan_sims(store, n, query, sims, st);
     HMM_LAUNCH_CHECK();
 
     if (p.full_sort) {
@@ -722,11 +798,7 @@ extern "C" int hmm_topk_merge_keys(const uint64_t* keys_dev, int n_shards, int k
 // Timing / test hook (include/hippomm_hip.h): the plain similarity pass alone.
 extern "C" int hmm_op_scan_sims(const float* store_dev, int64_t n_rows, const float* query_dev, float* sims_dev,
                                  hmm_stream_t stream) {
-    int64_t waves_needed = (n_rows + 1) / 2;
-    int blocks = (int)((waves_needed + 3) / 4);
-    if (blocks > g_sims_blocks) blocks = g_sims_blocks;
-    scan_sims_kernel<true><<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
-        reinterpret_cast<const float4*>(store_dev), n_rows, reinterpret_cast<const float4*>(query_dev), sims_dev);
+    launch_scan_sims(store_dev, n_rows, query_dev, sims_dev, static_cast<hipStream_t>(stream));
     HMM_LAUNCH_CHECK();
     return HMM_OK;
 }
@@ -765,11 +837,7 @@ extern "C" int hmm_cosine_topk_segmented(const float* store_dev, int64_t n_rows,
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* sims = static_cast<float*>(workspace_dev);
     if (n_rows > 0) {
-        int64_t waves_needed = (n_rows + 1) / 2;
-        int blocks = (int)((waves_needed + 3) / 4);
-        if (blocks > g_sims_blocks) blocks = g_sims_blocks;
-        scan_sims_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store_dev), n_rows,
-                                                       reinterpret_cast<const float4*>(query_dev), sims);
+        launch_scan_sims(store_dev, n_rows, query_dev, sims, st);
         HMM_LAUNCH_CHECK();
     }
     if (segments_are_small(n_rows, n_segments, k))
