@@ -647,8 +647,8 @@ static int run_scan(const float* store, int64_t n, int dim, const float* query, 
     HMM_REQUIRE(n >= 1 && n < (int64_t)0xFFFFFFFFll, HMM_E_INVALID, "cosine_topk: n_rows=%lld out of range", (long long)n);
     HMM_REQUIRE(k >= 1, HMM_E_INVALID, "cosine_topk: k must be >= 1, got %d", k);
     HMM_REQUIRE(store && query && ws, HMM_E_INVALID, "cosine_topk: null pointer");
-    HMM_REQUIRE(((uintptr_t)store & 15) == 0 && ((uintptr_t)query & 15) == 0, HMM_E_INVALID,
-                "cosine_topk: store/query must be 16-byte aligned");
+    HMM_REQUIRE(((uintptr_t)store & 15) == 0 && ((uintptr_t)query & 15) == 0 && ((uintptr_t)ws & 15) == 0, HMM_E_INVALID,
+                "cosine_topk: store, query and workspace must be 16-byte aligned");
     const ScanPlan p = make_plan(n, k);
     HMM_REQUIRE(ws_bytes >= p.total, HMM_E_WORKSPACE, "cosine_topk: workspace %zu < required %zu", ws_bytes, p.total);
     char* base = static_cast<char*>(ws);
@@ -798,6 +798,7 @@ extern "C" int hmm_topk_merge_keys(const uint64_t* keys_dev, int n_shards, int k
 // Timing / test hook (include/hippomm_hip.h): the plain similarity pass alone.
 extern "C" int hmm_op_scan_sims(const float* store_dev, int64_t n_rows, const float* query_dev, float* sims_dev,
                                  hmm_stream_t stream) {
+    HMM_REQUIRE(((uintptr_t)sims_dev & 15) == 0, HMM_E_INVALID, "scan_sims: sims_dev must be 16-byte aligned");
     launch_scan_sims(store_dev, n_rows, query_dev, sims_dev, static_cast<hipStream_t>(stream));
     HMM_LAUNCH_CHECK();
     return HMM_OK;
@@ -834,6 +835,7 @@ extern "C" int hmm_cosine_topk_segmented(const float* store_dev, int64_t n_rows,
     HMM_REQUIRE(n_rows == 0 || store_dev, HMM_E_INVALID, "cosine_topk_segmented: null store");
     HMM_REQUIRE(workspace_bytes >= hmm_cosine_topk_segmented_workspace_bytes(n_rows, n_segments, k), HMM_E_WORKSPACE,
                 "cosine_topk_segmented: workspace too small");
+    HMM_REQUIRE(((uintptr_t)workspace_dev & 15) == 0, HMM_E_INVALID, "cosine_topk_segmented: workspace must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* sims = static_cast<float*>(workspace_dev);
     if (n_rows > 0) {

@@ -30,6 +30,7 @@ namespace hmm {
 // waves than the fp32 scan, 768 workgroups: 0.3327 -> 0.3199 ms per query (640: 0.3202, 512: 0.328, 384: 0.390; profiles/r6_scan_blocks.json)
 HMM_TUNABLE(int, g_prefilter_blocks, kNumCU * 3)       // prefilter_topk_kernel
 HMM_TUNABLE(int, g_prefilter_sims_blocks, kScanBlocks) // prefilter_sims_kernel
+HMM_TUNABLE(int, g_prefilter_sims_deferred, 1)         // prefilter_sims_deferred_kernel instead of it
 constexpr float kPrefilterEps = 0.0040f;
 constexpr int kPrefilterCap = 1024;           // candidate rows pass 2 re-scores itself (16 waves)
 constexpr int kPrefilterMaxK = 64;
@@ -368,6 +369,65 @@ __global__ __launch_bounds__(256) void prefilter_sims_kernel(const uint4* __rest
     }
 }
 
+// The same pass with prefilter_topk_kernel's row dealing and no store in its loop (scan_sims_deferred_kernel's reason: stores mixed
+// into the read stream cost more than they weigh): lane l of four registers keeps the four results of iteration 64 j + l, one burst
+// of 16-byte stores per 256 iterations.  Same arithmetic per row, same bits.
+constexpr int kPrefilterSimsHeld = 4;
+__global__ __launch_bounds__(256) void prefilter_sims_deferred_kernel(const uint4* __restrict__ shadow, int64_t n_rows,
+                                                                      const float4* __restrict__ query, float* __restrict__ sims) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    float4 q[4];
+    float qs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 t = query[j * 64 + lane];
+        qs = fmaf(t.x, t.x, qs); qs = fmaf(t.y, t.y, qs); qs = fmaf(t.z, t.z, qs); qs = fmaf(t.w, t.w, qs);
+    }
+    q[0] = query[2 * lane]; q[1] = query[2 * lane + 1]; q[2] = query[128 + 2 * lane]; q[3] = query[128 + 2 * lane + 1];
+    const float inv_qlen = 1.0f / sqrtf(wave_sum(qs));
+    for (int64_t it0 = 0; (wave + it0 * n_waves) * 4 < n_rows; it0 += 64 * kPrefilterSimsHeld) {
+        float h[kPrefilterSimsHeld][4];
+#pragma unroll
+        for (int j = 0; j < kPrefilterSimsHeld; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[j][i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < kPrefilterSimsHeld; ++j) {
+            for (int l = 0; l < 64; ++l) {
+                const int64_t r0 = (wave + (it0 + j * 64 + l) * n_waves) * 4;
+                if (r0 >= n_rows) break;                                     // wave-uniform; every later iteration is past the end too
+                uint4 x[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint4* p = shadow + (r0 + i < n_rows ? r0 + i : r0) * 128 + lane;
+                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+                    const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 64));
+                    x[i][0] = make_uint4(a[0], a[1], a[2], a[3]);
+                    x[i][1] = make_uint4(b[0], b[1], b[2], b[3]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = wave_sum(dot8_bf16(x[i][1], q[2], q[3], dot8_bf16(x[i][0], q[0], q[1], 0.f))) * inv_qlen;
+                    h[j][i] = lane == l ? d : h[j][i];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kPrefilterSimsHeld; ++j) {
+            const int64_t r0 = (wave + (it0 + j * 64 + lane) * n_waves) * 4;
+            if (r0 + 3 < n_rows) {
+                *reinterpret_cast<float4*>(sims + r0) = make_float4(h[j][0], h[j][1], h[j][2], h[j][3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (r0 + i < n_rows) sims[r0 + i] = h[j][i];
+            }
+        }
+    }
+}
+
 // pass 2: one workgroup per event.  The event's k-th largest s~ gives the threshold, the rows at or above it are re-scored on the
 // fp32 store (exact_row_sim) and the k best of those are the event's answer -- what segment_topk_kernel returns on the exact
 // similarities.  More candidates than the buffer holds (an event of near-identical rows): every row of the event is re-scored.
@@ -569,11 +629,19 @@ extern "C" int hmm_cosine_topk_segmented_prefilter(const float* store_dev, const
     HMM_REQUIRE(workspace_bytes >= hmm_cosine_topk_segmented_prefilter_workspace_bytes(n_rows, n_segments, k), HMM_E_WORKSPACE,
                 "cosine_topk_segmented_prefilter: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    HMM_REQUIRE(((uintptr_t)workspace_dev & 15) == 0, HMM_E_INVALID, "cosine_topk_segmented_prefilter: workspace must be 16-byte aligned");
     float* sims = static_cast<float*>(workspace_dev);
-    int64_t blocks = (n_rows + 127) / 128;                                  // 4 waves x 32 rows
-    if (blocks > g_prefilter_sims_blocks) blocks = g_prefilter_sims_blocks;
-    prefilter_sims_kernel<<<(unsigned)blocks, 256, 0, st>>>(static_cast<const uint4*>(shadow_dev), n_rows,
-                                                            reinterpret_cast<const float4*>(query_dev), sims);
+    if (g_prefilter_sims_deferred) {
+        int64_t blocks = (n_rows + 15) / 16;                                // 4 waves x 4 rows
+        if (blocks > g_prefilter_blocks) blocks = g_prefilter_blocks;
+        prefilter_sims_deferred_kernel<<<(unsigned)blocks, 256, 0, st>>>(static_cast<const uint4*>(shadow_dev), n_rows,
+                                                                         reinterpret_cast<const float4*>(query_dev), sims);
+    } else {                                                                // (what the probe build's knob compares against)
+        int64_t blocks = (n_rows + 127) / 128;                              // 4 waves x 32 rows
+        if (blocks > g_prefilter_sims_blocks) blocks = g_prefilter_sims_blocks;
+        prefilter_sims_kernel<<<(unsigned)blocks, 256, 0, st>>>(static_cast<const uint4*>(shadow_dev), n_rows,
+                                                                reinterpret_cast<const float4*>(query_dev), sims);
+    }
     HMM_LAUNCH_CHECK();
     if (segments_are_small(n_rows, n_segments, k))          // the two shapes of segment_topk_kernel, for the same reason
         segment_prefilter_kernel<kSmallSegChunk, 256><<<n_segments, 256, 0, st>>>(

@@ -42,6 +42,9 @@ extern "C" {
 
 typedef void* hmm_stream_t;   /* hipStream_t */
 
+/* Alignment: stores, queries and workspaces (*_dev) must be 16-byte aligned -- anything hipMalloc or a torch allocation returns is
+ * 256-byte aligned; a pointer into the middle of such a buffer must keep the 16 bytes.  Refused with HMM_E_INVALID otherwise. */
+
 int         hmm_abi_version(void);
 const char* hmm_last_error(void);
 /* HMM_OK when the current HIP device is what this library is built for (gfx950 with 256 compute units: the launch
