@@ -234,6 +234,18 @@ def test_error_codes_through_the_c_abi():
     assert seg(0, k) == -1 and b"n_segments" in lib.hmm_last_error()
     assert seg(-2, k) == -1
     assert seg(1, 0) == -1
+    # a workspace that lost its 16-byte alignment is refused (include/hippomm_hip.h, Alignment), here and by the exact entry points
+    big = torch.empty(seg_ws.numel() + max(lib.hmm_cosine_topk_segmented_workspace_bytes(n, 1, k), lib.hmm_cosine_topk_workspace_bytes(n, k)) + 64,
+                      dtype=torch.uint8, device="cuda")
+    assert lib.hmm_cosine_topk_segmented_prefilter(rows.data_ptr(), shadow.data_ptr(), n, 1024, q.data_ptr(), offs.data_ptr(), 1, k, idx.data_ptr(),
+                                                   sims.data_ptr(), n_out.data_ptr(), big.data_ptr() + 4, big.numel() - 4, st) == -1
+    assert b"aligned" in lib.hmm_last_error()
+    assert lib.hmm_cosine_topk_segmented(rows.data_ptr(), n, 1024, q.data_ptr(), offs.data_ptr(), 1, k, idx.data_ptr(), sims.data_ptr(),
+                                         n_out.data_ptr(), big.data_ptr() + 8, big.numel() - 8, st) == -1
+    assert lib.hmm_cosine_topk(rows.data_ptr(), n, 1024, q.data_ptr(), k, idx.data_ptr(), sims.data_ptr(), n_out.data_ptr(),
+                               big.data_ptr() + 4, big.numel() - 4, st) == -1
+    assert lib.hmm_cosine_topk(rows.data_ptr(), n, 1024, q.data_ptr(), k, idx.data_ptr(), sims.data_ptr(), n_out.data_ptr(),
+                               big.data_ptr() + 16, big.numel() - 16, st) == 0
 
 
 def test_feature_store_with_shadow_serves_the_drop_in_call_identically():
