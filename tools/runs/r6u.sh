@@ -16,6 +16,7 @@ echo "pmc rc=$?"; tail -3 $OUT/pmc.log
 timeout 900 python tools/rehearse_n8.py $OUT/rehearsal_8_ranks.json > $OUT/rehearse.log 2>&1
 echo "rehearse rc=$?"; tail -2 $OUT/rehearse.log
 timeout 900 python tools/prefilter_stress.py 1000 > $OUT/stress.log 2>&1; echo "stress rc=$?"; tail -4 $OUT/stress.log
+timeout 900 python tools/stress_determinism.py > $OUT/stress_determinism.log 2>&1; echo "determinism rc=$?"; tail -5 $OUT/stress_determinism.log
 timeout 1500 python tools/dispatch_audit_probe.py --check $OUT/dispatch_recheck.json > $OUT/recheck.log 2>&1
 echo "recheck rc=$?"; grep '"keep"' $OUT/recheck.log | python3 -c "
 import sys, json
