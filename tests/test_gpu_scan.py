@@ -164,6 +164,30 @@ def test_full_size_properties_1m_rows():
     np.testing.assert_allclose(sims_h, o_sims, rtol=0, atol=SIM_ATOL)
 
 
+def test_similarity_pass_of_a_store_larger_than_one_epoch():
+    """hmm_op_scan_sims (the similarity pass of the per-event scan and of k > 128) keeps its results in registers and writes them
+    once per 512 iterations: 1.7M rows need a second epoch on the scan's grid (1536 waves x 2 rows x 512 = 1 572 864 rows per
+    epoch).  Every similarity against torch within the scan's tolerance, and the rows around and beyond the epoch boundary bitwise
+    equal to the same rows scanned as a store of their own (one epoch): a row's arithmetic does not depend on where it sits."""
+    from hippomm_amd import _lib as L
+    lib = L.load()
+    n = 1_700_000 + 3                                        # odd: the last pair has one row
+    g = torch.Generator(device="cuda").manual_seed(7)
+    rows = torch.empty(n, 1024, dtype=torch.float32, device="cuda")
+    for s in range(0, n, 100_000):
+        m = min(100_000, n - s)
+        rows[s:s + m] = torch.randn(m, 1024, generator=g, device="cuda")
+    q = torch.randn(1024, generator=torch.Generator(device="cuda").manual_seed(8), device="cuda")
+    sims = torch.full((n,), -7.0, device="cuda")
+    L.check(lib.hmm_op_scan_sims(rows.data_ptr(), n, q.data_ptr(), sims.data_ptr(), L.stream_ptr()), "hmm_op_scan_sims")
+    want = (rows @ q) / (rows.norm(dim=1) * q.norm())
+    assert float((sims - want).abs().max()) <= SIM_ATOL
+    lo = 1_560_000                                           # 16-byte aligned start (lo x 4096 B), before the boundary
+    part = torch.empty(n - lo, device="cuda")
+    L.check(lib.hmm_op_scan_sims(rows[lo:].data_ptr(), n - lo, q.data_ptr(), part.data_ptr(), L.stream_ptr()), "hmm_op_scan_sims")
+    assert torch.equal(part.view(torch.int32), sims[lo:].view(torch.int32))
+
+
 def test_store_cache_keeps_numpy_stores_resident_and_notices_what_it_can():
     """enable_store_cache(): the reference's unchanged per-event loop passes the same host arrays question after question; they
     are served from HBM from the second call on, rebuilt when the array object, its buffer or a sampled element changed, released
