@@ -177,6 +177,30 @@ def test_per_event_prefilter_equals_the_exact_per_event_scan(sizes, k):
     assert torch.equal(s0.view(torch.int32), s1.view(torch.int32))
 
 
+def test_per_event_prefilter_on_a_store_larger_than_one_epoch_of_its_similarity_pass():
+    """prefilter_sims_deferred_kernel writes its results once per 256 iterations: 768 workgroups x 4 waves x 4 rows x 256 =
+    3 145 728 rows per epoch.  3.2M rows in events of 500: the per-event answer through the shadow equals the exact one (indices,
+    similarity bits, counts) on both sides of the boundary and in the ragged last event."""
+    from hippomm_amd.vector_ops import EventStore
+    n = 3_200_000 + 7
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rows = torch.empty(n, 1024, dtype=torch.float32, device="cuda")
+    for s in range(0, n, 100_000):
+        m = min(100_000, n - s)
+        rows[s:s + m] = torch.randn(m, 1024, generator=g, device="cuda")
+    sizes = [500] * (n // 500) + [n % 500]
+    es = EventStore.from_device_rows(rows, sizes)
+    q = torch.randn(1024, generator=torch.Generator(device="cuda").manual_seed(12), device="cuda")
+    i0, s0, c0 = es.search_segments_device(q, es.offsets, 5)
+    i1, s1, c1 = es.search_segments_device(q, es.offsets, 5, prefilter=True)
+    assert torch.equal(c0, c1) and torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    e = 3_145_728 // 500                                      # the event that straddles the epoch boundary: against torch
+    lo = e * 500
+    ev = rows[lo:lo + 500]
+    want = torch.topk((ev @ q) / (ev.norm(dim=1) * q.norm()), 5)
+    assert i1[e].tolist() == want.indices.tolist()
+
+
 def test_per_event_prefilter_on_events_of_near_identical_rows():
     """Every event is one scene: 300 frames within 1e-3 of each other, so every row of an event is a candidate (more than the
     candidate buffer for the large event) and the whole event is re-scored; the answer must still be the exact one."""
