@@ -10,7 +10,6 @@ call, which is correct but PCIe-bound.
 """
 from __future__ import annotations
 
-import ctypes as C
 import threading
 import weakref
 import zlib
