@@ -24,8 +24,9 @@ constexpr int kFastK = 1024;      // chunk-tournament path handles k <= kFastK
 // flight (~7 TB/s x 1.5 us = ~11 MB): scan_topk_kernel keeps 8 KB per wave in flight, so ~1536 waves = 384 workgroups are enough, and
 // MORE of them stream slower -- 2048 workgroups 0.613 ms, 512: 0.598, 384: 0.579 (= the 0.885 of 8 TB/s a pure reader gets), 336:
 // 0.597, 256: 0.721 on 1M rows in one session, a smooth bowl around 384 on two boxes (profiles/r6_scan_blocks.json).  Until round 6
-// the grid was "eight workgroups per CU" by habit.  The similarity pass (scan_sims_kernel, 32 rows per wave and visit) has no such
-// optimum (0.651 ... 0.72 ms, 2048 among the best; the kernel alone 0.601-0.619 ms from 256 to 2048 workgroups) and keeps its grid.
+// the grid was "eight workgroups per CU" by habit.  The similarity pass that ships (scan_sims_deferred_kernel) deals rows the same way
+// and runs on the same grid; its predecessor scan_sims_kernel (32 rows per wave and visit, a store per visit) has no such optimum
+// (0.601-0.619 ms from 256 to 2048 workgroups) and keeps 2048 where the probe build still runs it.
 HMM_TUNABLE(int, g_scan_blocks, kNumCU * 3 / 2)   // scan_topk_kernel
 HMM_TUNABLE(int, g_sims_blocks, kScanBlocks)      // scan_sims_kernel
 HMM_TUNABLE(int, g_sims_deferred, 1)               // scan_sims_deferred_kernel wherever the store fits it
@@ -330,7 +331,7 @@ __device__ __forceinline__ void top64_of_stream(uint64_t* w, int n_keys, F key_a
 }
 
 // The exact scan as the CONDITIONAL FALLBACK of the bf16-prefilter path (cosine_topk_prefilter.hip), one launch with its own symbol:
-// returns at once unless *run_if != 0 (the usual case: 2048 workgroups that exit, ~4 us); otherwise scan_topk_kernel's streaming body,
+// returns at once unless *run_if != 0 (the usual case: the scan's 384 workgroups exit, ~4.5 us); otherwise scan_topk_kernel's streaming body,
 // and the workgroup that takes the last ticket (device-scope counter, zeroed by prefilter_final_kernel) finishes as topk_final_kernel
 // does -- the k lists with the largest maxima hold the answer -- in the 8 KB of LDS the streaming body already has.  k <= 64.
 __global__ __launch_bounds__(256) void exact_scan_fallback_kernel(const float4* __restrict__ store, int64_t n_rows,
