@@ -3,10 +3,12 @@
 // Replaces top_k_cosine_similarity (reference hippomm/utils/vector_ops.py:151-188).
 //
 // Kernels
-//   scan_sims_kernel   HBM-bound.  One wave per row: lane l reads the four float4 at
+//   scan_topk_kernel   HBM-bound (k <= 128, the usual query).  One wave per row: lane l reads the four float4 at
 //                      columns 4*(64*j + l), j=0..3, so every load instruction of a wave covers
 //                      1 KiB contiguous.  Two rows (8 x 16 B loads per lane) are in flight per
-//                      wave, 32 waves per CU.  Algorithmic bytes: 4096 B per row, read once.
+//                      wave; block-local top-k lists, topk_final_kernel finishes.  Algorithmic bytes: 4096 B per row, read once.
+//   scan_sims_deferred_kernel  the same pass writing every similarity (per-event scan, k > 128): results held in registers,
+//                      one burst of stores per 512 iterations.
 //   topk_chunk_kernel  4096-key bitonic sort in LDS per block, keeps the best k of each chunk;
 //                      applied repeatedly until one chunk is left (N=1M, k=32: 245 -> 2 -> 1).
 //   bitonic_global_*   rare path (k > 1024 and N > 4096): full sort of all keys.
@@ -28,14 +30,17 @@ constexpr int kFastK = 1024;      // chunk-tournament path handles k <= kFastK
 // and runs on the same grid; its predecessor scan_sims_kernel (32 rows per wave and visit, a store per visit) has no such optimum
 // (0.601-0.619 ms from 256 to 2048 workgroups) and keeps 2048 where the probe build still runs it.
 HMM_TUNABLE(int, g_scan_blocks, kNumCU * 3 / 2)   // scan_topk_kernel
-HMM_TUNABLE(int, g_sims_blocks, kScanBlocks)      // scan_sims_kernel
-HMM_TUNABLE(int, g_sims_deferred, 1)               // scan_sims_deferred_kernel wherever the store fits it
+#ifdef HMM_PROBE
+HMM_TUNABLE(int, g_sims_blocks, kScanBlocks)      // scan_sims_kernel (probe build only)
+HMM_TUNABLE(int, g_sims_deferred, 1)               // 0: scan_sims_kernel instead of scan_sims_deferred_kernel (probe build only)
+#endif
 HMM_TUNABLE(int, g_small_segment_rows, 1024)      // mean rows per event up to which the small per-event selection kernels run
 
 bool segments_are_small(int64_t n_rows, int n_segments, int k) {
     return k <= 64 && n_segments >= 1 && n_rows <= (int64_t)n_segments * g_small_segment_rows;
 }
 
+#ifdef HMM_PROBE   // the similarity pass until round 6, kept in the probe build as what scan_sims_deferred_kernel is measured against
 // sims[r] = dot(store[r], q) / (||store[r]|| * ||q||)     (vector_ops.py:178-182)
 // (at most six waves per SIMD, all eight loads of a row pair in flight: see scan_topk_kernel)
 template <bool NT>
@@ -91,9 +96,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 6))) voi
         if (lane < 32 && base + lane < n_rows) sims[base + lane] = mine;
     }
 }
+#endif  // HMM_PROBE
 
-// The same similarities with scan_topk_kernel's row dealing (pair p belongs to wave p % n_waves: at any moment the waves of the chip
-// read one contiguous window of the store) and NO store inside the loop: lane l of two registers keeps the results of iteration
+// sims[r] = dot(store[r], q) / (||store[r]|| * ||q||)     (vector_ops.py:178-182)
+// scan_topk_kernel's row dealing (pair p belongs to wave p % n_waves: at any moment the waves of the chip read one contiguous window
+// of the store; at most six waves per SIMD, all eight loads of a row pair in flight) and NO store inside the loop: lane l of two registers keeps the results of iteration
 // 64 j + l, and the wave writes everything it computed when it has read its last row.  Stores mixed into the read stream are what
 // scan_sims_kernel pays for: groups of 32 rows with one 128-B line of results each 0.606 ms per pass, the same without its stores
 // 0.589, this dealing with an 8-byte store per pair in the loop 0.621, without any 0.573 (scan_topk_kernel) -- and deferred: see
@@ -154,18 +161,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 6))) voi
     }
 }
 
-// All similarities of a store into sims[] (scan_sims_kernel is what the probe build's knob compares against).
+// All similarities of a store into sims[].
 static void launch_scan_sims(const float* store, int64_t n, const float* query, float* sims, hipStream_t st) {
     int64_t waves_needed = (n + 1) / 2;
     int blocks = (int)((waves_needed + 3) / 4);
-    if (g_sims_deferred) {
-        if (blocks > g_scan_blocks) blocks = g_scan_blocks;
-        scan_sims_deferred_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n,
-                                                                reinterpret_cast<const float4*>(query), sims);
+#ifdef HMM_PROBE
+    if (!g_sims_deferred) {
+        if (blocks > g_sims_blocks) blocks = g_sims_blocks;
+        scan_sims_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n, reinterpret_cast<const float4*>(query), sims);
         return;
     }
-    if (blocks > g_sims_blocks) blocks = g_sims_blocks;
-    scan_sims_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n, reinterpret_cast<const float4*>(query), sims);
+#endif
+    if (blocks > g_scan_blocks) blocks = g_scan_blocks;
+    scan_sims_deferred_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(store), n,
+                                                            reinterpret_cast<const float4*>(query), sims);
 }
 
 // Descending bitonic sort of N keys in LDS by NT threads.

@@ -29,8 +29,10 @@ namespace hmm {
 // Workgroups of the bf16 passes (see g_scan_blocks in cosine_topk.hip): the shadow pass does more arithmetic per byte and wants more
 // waves than the fp32 scan, 768 workgroups: 0.3327 -> 0.3199 ms per query (640: 0.3202, 512: 0.328, 384: 0.390; profiles/r6_scan_blocks.json)
 HMM_TUNABLE(int, g_prefilter_blocks, kNumCU * 3)       // prefilter_topk_kernel
-HMM_TUNABLE(int, g_prefilter_sims_blocks, kScanBlocks) // prefilter_sims_kernel
-HMM_TUNABLE(int, g_prefilter_sims_deferred, 1)         // prefilter_sims_deferred_kernel instead of it
+#ifdef HMM_PROBE
+HMM_TUNABLE(int, g_prefilter_sims_blocks, kScanBlocks) // prefilter_sims_kernel (probe build only)
+HMM_TUNABLE(int, g_prefilter_sims_deferred, 1)         // 0: prefilter_sims_kernel instead of prefilter_sims_deferred_kernel (probe build only)
+#endif
 constexpr float kPrefilterEps = 0.0040f;
 constexpr int kPrefilterCap = 1024;           // candidate rows pass 2 re-scores itself (16 waves)
 constexpr int kPrefilterMaxK = 64;
@@ -328,6 +330,7 @@ static int prefilter_list_len(int k) {
 }
 
 // ---- per-event variant (hmm_cosine_topk_segmented through the shadow) -------------------------------------------------------
+#ifdef HMM_PROBE   // the pass until round 6, kept in the probe build as what prefilter_sims_deferred_kernel is measured against
 // pass 1: s~ of every row, written as whole 128-B lines (a wave takes 32 consecutive rows, four at a time)
 __global__ __launch_bounds__(256) void prefilter_sims_kernel(const uint4* __restrict__ shadow, int64_t n_rows,
                                                              const float4* __restrict__ query, float* __restrict__ sims) {
@@ -368,9 +371,10 @@ __global__ __launch_bounds__(256) void prefilter_sims_kernel(const uint4* __rest
         if (lane < 32 && base + lane < n_rows) sims[base + lane] = mine;
     }
 }
+#endif  // HMM_PROBE
 
-// The same pass with prefilter_topk_kernel's row dealing and no store in its loop (scan_sims_deferred_kernel's reason: stores mixed
-// into the read stream cost more than they weigh): lane l of four registers keeps the four results of iteration 64 j + l, one burst
+// pass 1: s~ of every row, with prefilter_topk_kernel's row dealing and no store in its loop (scan_sims_deferred_kernel's reason:
+// stores mixed into the read stream cost more than they weigh): lane l of four registers keeps the four results of iteration 64 j + l, one burst
 // of 16-byte stores per 256 iterations.  Same arithmetic per row, same bits.
 constexpr int kPrefilterSimsHeld = 4;
 __global__ __launch_bounds__(256) void prefilter_sims_deferred_kernel(const uint4* __restrict__ shadow, int64_t n_rows,
@@ -631,16 +635,21 @@ extern "C" int hmm_cosine_topk_segmented_prefilter(const float* store_dev, const
     hipStream_t st = static_cast<hipStream_t>(stream);
     HMM_REQUIRE(((uintptr_t)workspace_dev & 15) == 0, HMM_E_INVALID, "cosine_topk_segmented_prefilter: workspace must be 16-byte aligned");
     float* sims = static_cast<float*>(workspace_dev);
-    if (g_prefilter_sims_deferred) {
-        int64_t blocks = (n_rows + 15) / 16;                                // 4 waves x 4 rows
-        if (blocks > g_prefilter_blocks) blocks = g_prefilter_blocks;
-        prefilter_sims_deferred_kernel<<<(unsigned)blocks, 256, 0, st>>>(static_cast<const uint4*>(shadow_dev), n_rows,
-                                                                         reinterpret_cast<const float4*>(query_dev), sims);
-    } else {                                                                // (what the probe build's knob compares against)
+    bool deferred = true;
+#ifdef HMM_PROBE
+    deferred = g_prefilter_sims_deferred != 0;
+    if (!deferred) {
         int64_t blocks = (n_rows + 127) / 128;                              // 4 waves x 32 rows
         if (blocks > g_prefilter_sims_blocks) blocks = g_prefilter_sims_blocks;
         prefilter_sims_kernel<<<(unsigned)blocks, 256, 0, st>>>(static_cast<const uint4*>(shadow_dev), n_rows,
                                                                 reinterpret_cast<const float4*>(query_dev), sims);
+    }
+#endif
+    if (deferred) {
+        int64_t blocks = (n_rows + 15) / 16;                                // 4 waves x 4 rows
+        if (blocks > g_prefilter_blocks) blocks = g_prefilter_blocks;
+        prefilter_sims_deferred_kernel<<<(unsigned)blocks, 256, 0, st>>>(static_cast<const uint4*>(shadow_dev), n_rows,
+                                                                         reinterpret_cast<const float4*>(query_dev), sims);
     }
     HMM_LAUNCH_CHECK();
     if (segments_are_small(n_rows, n_segments, k))          // the two shapes of segment_topk_kernel, for the same reason

@@ -43,6 +43,10 @@ knobs = {"g_scan_blocks": ("exact_query", lambda: store.search_device(q, K)),
          "g_sims_blocks": ("per_event", lambda: events.search_segments_device(q, events.offsets, 5)),
          "g_prefilter_blocks": ("prefilter_query", lambda: store.search_prefiltered_device(q, K)),
          "g_prefilter_sims_blocks": ("per_event_prefilter", lambda: events.search_segments_device(q, events.offsets, 5, prefilter=True))}
+# g_sims_blocks / g_prefilter_sims_blocks size the similarity passes of UNTIL round 6 (scan_sims_kernel, prefilter_sims_kernel), which
+# only the probe build still has: switch to them for this sweep (the shipped deferred-store passes run on g_scan_blocks / g_prefilter_blocks)
+setter(lib, "g_sims_deferred")(0)
+setter(lib, "g_prefilter_sims_deferred")(0)
 out = {}
 for knob, (leg, fn) in knobs.items():
     set_k = setter(lib, knob)
